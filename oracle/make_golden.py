@@ -1,0 +1,231 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation.
+
+Run only in the authoring container (needs /root/reference); the GPU box never
+runs this.  The reference's heavy optional imports (pytorch_lightning, rdkit,
+dgl, wandb, ...) are not installed, so they are served as inert stub modules;
+only torch arithmetic of the reference is executed.  Weights are regenerated
+from a seed by oracle.mmt_oracle.make_state_dict and loaded into the reference
+module with load_state_dict, so the fixtures hold inputs and outputs only.
+
+    python oracle/make_golden.py
+"""
+import argparse
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import mmt_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+MISSING = {'pytorch_lightning', 'rdkit', 'dgl', 'dgllife', 'wandb', 'cairosvg', 'IPython', 'nmr_sgnn_norm',
+           'molvs', 'umap'}
+
+
+class _Loader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__name__ = spec.name
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__loader__ = self
+        if spec.name == 'pytorch_lightning':
+            m.LightningModule = torch.nn.Module
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path, target=None):
+        if name.split('.')[0] in MISSING:
+            return importlib.machinery.ModuleSpec(name, _Loader(), is_package=True)
+
+
+def import_reference():
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, REF)
+    sg = types.ModuleType('utils_MMT.sgnn_code_pl_v15_4')
+    sg.load_std_mean = lambda t, g: (0.0, 1.0)
+    sg.main_execute = None
+    sys.modules['utils_MMT.sgnn_code_pl_v15_4'] = sg
+    bl = types.ModuleType('utils_MMT.models_BLIP_v15_4')
+    bl.BLIPMultiGPU = None
+    sys.modules['utils_MMT.models_BLIP_v15_4'] = bl
+    import utils_MMT.models_MMT_v15_4 as M
+    import utils_MMT.validate_generate_MMT_v15_4 as vg
+    import utils_MMT.helper_functions_pl_v15_4 as hf
+    import utils_MMT.dataloaders_pl_v15_4 as dl
+    return M, vg, hf, dl
+
+
+def ref_config(**over):
+    cfg = {k: v[0] for k, v in json.load(open(f'{REF}/utils_MMT/config_V8.json')).items()}
+    cfg.update(device='cpu', model_save_dir='/tmp/mmt_golden', itos_path=f'{REF}/itos.json',
+               stoi_path=f'{REF}/stoi.json', itos_MF_path=f'{REF}/itos_MF.json',
+               stoi_MF_path=f'{REF}/stoi_MF.json')
+    cfg.update(over)
+    return argparse.Namespace(**cfg)
+
+
+def call_model(model, mode, b, trg=None):
+    g = lambda k, tag: b[k] if tag in mode else None  # noqa: E731
+    return model(g('src_1H', '1H'), g('mask_1H', '1H'), g('src_13C', '13C'), g('mask_13C', '13C'),
+                 g('src_HSQC', 'HSQC'), g('mask_HSQC', 'HSQC'), g('src_COSY', 'COSY'), g('mask_COSY', 'COSY'),
+                 g('src_IR', 'IR'), g('mask_IR', 'IR'), g('src_MF', 'MF'), g('mask_MF', 'MF'),
+                 g('src_MS', 'MS'), g('mask_MS', 'MS'), b['trg_MW'], trg)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def digest(t, n=96):
+    """Small stand-in for a big tensor: [sum, sum|x|, sum x^2] + n strided samples
+    (indices linspace(0, numel-1, n)).  tests/ recompute the same digest."""
+    a = np_(t).astype(np.float64).reshape(-1)
+    idx = np.linspace(0, a.size - 1, min(n, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
+
+
+def forward_case(M, name, mode, nl, B, seed, wseed, with_grads=True, steps=0):
+    torch.manual_seed(0)
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.0)
+    model = M.MultimodalTransformer(cfg)
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    sd = O.make_state_dict(ocfg, wseed)
+    assert list(sd.keys()) == list(model.state_dict().keys()), "state_dict key order differs"
+    model.load_state_dict(sd)
+    # eval mode: the encoder/decoder layers carry torch's default dropout 0.1 whatever config.drop_out
+    # says (models_MMT_v15_4.py:510-541 pass only d_model and nhead), so only eval is deterministic.
+    # Gradients still flow in eval mode (torch's inference fast path is off when grad is required).
+    model.eval()
+    b = O.synthetic_batch(B, seed, mode)
+    trg = b['trg_enc_SMI'].t()
+    out = {}
+    logits, fp, memory, mask = call_model(model, mode, b, trg[:-1, :])
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, logits.shape[-1]), trg[1:, :].reshape(-1))
+    out.update(logits=np_(logits), fingerprint=np_(fp), memory=digest(memory, 512), mask=np_(mask.float()),
+               loss=np_(loss), seed=np.int64(seed), wseed=np.int64(wseed), B=np.int64(B), nl=np.int64(nl))
+    mem2, emb_src, mask2, fp2 = call_model(model, mode, b, None)
+    out.update(embedding_src=digest(emb_src, 512))
+    if with_grads:
+        loss.backward()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        for k in grads:
+            if grads[k] is not None:
+                out['grad/' + k] = digest(grads[k])
+        out['nograd'] = np.array([k for k in grads if grads[k] is None])
+    if steps:
+        opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr_pretraining)
+        losses = [float(loss)]
+        opt.step()
+        for _ in range(steps - 1):
+            opt.zero_grad()
+            logits, fp, memory, mask = call_model(model, mode, b, trg[:-1, :])
+            loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, logits.shape[-1]), trg[1:, :].reshape(-1))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        out['step_losses'] = np.array(losses, np.float64)
+        post = model.state_dict()
+        for k in ('fc_out.weight', 'decoder.layers.0.linear1.weight', 'encoder_cross.layers.0.self_attn.in_proj_weight',
+                  'encoder_1H.layers.0.norm1.weight', 'embed_trg.weight',
+                  'linear_spec_embedding_1H.point_embedding_layer_1H.fc_H.weight'):
+            out['post/' + k] = digest(post[k])
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+    print(name, 'loss', float(out['loss']), 'logits', out['logits'].shape)
+
+
+def greedy_case(M, vg, name, mode, nl, B, seed, wseed, gain):
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.1)
+    model = M.MultimodalTransformer(cfg)
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    model.load_state_dict(O.make_state_dict(ocfg, wseed, logit_gain=gain))
+    model.eval()
+    b = O.synthetic_batch(B, seed, mode)
+    b['src_HSQC_'] = b['src_HSQC']
+    b['src_COSY_'] = b['src_COSY']
+    if 'MW' in mode:
+        memory, mask, trg, fp, _, _ = vg.run_model(model, b, cfg)
+    else:  # run_model cannot run without MW in the mode (it unsqueezes None)
+        with torch.no_grad():
+            memory, _, mask, fp = call_model(model, mode, b, None)
+    stoi = json.load(open(f'{REF}/stoi.json'))
+    itos = json.load(open(f'{REF}/itos.json'))
+    toks, probs = vg.greedy_sequence(model, stoi, itos, memory, mask, cfg)
+    import utils_MMT.helper_functions_pl_v15_4 as hf
+    smiles = hf.tensor_to_smiles(toks, itos)
+    # margins from the oracle (used by bf16 tests as a guard); tokens from the reference
+    sd = {k: v for k, v in model.state_dict().items()}
+    otoks, oprobs, margins = O.greedy_sequence(sd, ocfg, memory, mask)
+    assert torch.equal(otoks, toks), "oracle greedy differs from reference"
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'),
+                        tokens=np_(toks), probs=np_(probs), memory=digest(memory, 512), mask=np_(mask.float()),
+                        fingerprint=np_(fp), margins=np_(margins), smiles=np.array(smiles),
+                        seed=np.int64(seed), wseed=np.int64(wseed), B=np.int64(B), nl=np.int64(nl),
+                        gain=np.float64(gain))
+    print(name, 'steps', toks.shape, 'min margin', float(margins.min()), smiles[:2])
+
+
+def text_case(hf, dl):
+    stoi = json.load(open(f'{REF}/stoi.json'))
+    itos = json.load(open(f'{REF}/itos.json'))
+    stoi_MF = json.load(open(f'{REF}/stoi_MF.json'))
+    smiles = ['CC(=O)Nc1ccc(Cl)cc1', 'C[C@@H](N)C(=O)O', 'BrCCBr', 'c1ccsc1', 'C[N+](C)(C)CC(=O)[O-]',
+              'FC(F)(F)c1ccccc1I', 'CC#N', 'O=C1CCCN1', 'C/C=C/C', 'Sic1', 'NoOs', 'P(=O)(O)O', 'B1OB1', 'C%12']
+    formulas = ['C10H12N2O', 'C6H6', 'C2H4Br2', 'C20H25N3O', 'C8H9ClO', 'CH4', 'C100H202', 'C7H5F3IN']
+    ds = dl.MultimodalData.__new__(dl.MultimodalData)
+    enc = [ds._encode_smiles(stoi, s) for s in smiles]
+    enc_mf = [ds._encode_MF(stoi_MF, f) for f in formulas]
+    toks = [hf.tokenize_smiles(s, hf.two_char_symbols) for s in smiles]
+    # decode: build a (64, n) tensor of <SOS>-less ids + EOS + PAD and run the reference decoder
+    n = len(smiles)
+    t = torch.zeros(64, n, dtype=torch.long)
+    for i, e in enumerate(enc):
+        e = [x if x is not None else 1 for x in e]
+        t[:len(e), i] = torch.tensor(e)
+        t[len(e), i] = 2
+    dec = hf.tensor_to_smiles(t, itos)
+    rng = np.random.default_rng(7)
+    pads = {}
+    for n1 in (0, 1, 5, 63, 64, 80):
+        d1 = rng.uniform(0, 1, n1).tolist()
+        p, m = ds._zero_pad(d1, 64, dimensions=1) if n1 else (torch.zeros(64), torch.ones(64).long())
+        pads[f'pad1_{n1}'] = (d1, np_(p).tolist(), np_(m).tolist())
+        d2 = rng.uniform(0, 1, (n1, 2)).tolist()
+        p, m = ds._zero_pad(d2, 64, dimensions=2)
+        pads[f'pad2_{n1}'] = (d2, np_(p).tolist(), np_(m).tolist())
+    json.dump(dict(smiles=smiles, tokens=toks, ids=enc, formulas=formulas, mf_ids=enc_mf, decoded=dec,
+                   decode_input=t.tolist(), pads=pads),
+              open(os.path.join(ROOT, 'tests', 'golden', 'text.json'), 'w'))
+    print('text ok', dec[:3])
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
+    M, vg, hf, dl = import_reference()
+    torch.set_num_threads(8)
+    forward_case(M, 'fwd_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 3, seed=11, wseed=101, steps=2)
+    forward_case(M, 'fwd_c1_L2', '1H', 2, 4, seed=12, wseed=102)
+    forward_case(M, 'fwd_all_L1', '1H_13C_HSQC_COSY_IR_MF_MW', 1, 2, seed=13, wseed=103)
+    forward_case(M, 'fwd_ms_L1', '1H_13C_HSQC_COSY_IR_MF_MS_MW', 1, 2, seed=14, wseed=104)
+    forward_case(M, 'fwd_nomf_L1', '1H_HSQC_COSY_IR', 1, 2, seed=15, wseed=105)
+    forward_case(M, 'fwd_c2_L6', '1H_HSQC_COSY_IR_MF_MW', 6, 2, seed=16, wseed=106, with_grads=False)
+    greedy_case(M, vg, 'greedy_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 8, seed=21, wseed=201, gain=1.0)
+    greedy_case(M, vg, 'greedy_c1_L2', '1H', 2, 4, seed=22, wseed=202, gain=1.0)
+    text_case(hf, dl)
+
+
+if __name__ == '__main__':
+    main()

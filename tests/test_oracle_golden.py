@@ -1,0 +1,119 @@
+"""The CPU oracle against fixtures produced by the reference implementation itself
+(oracle/make_golden.py).  fp32 tolerance: logits atol 2e-5 (measured thread-count noise of
+the reference is 1.2e-6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmt_oracle as O
+from tests.util import GOLDEN, digest, digest_close, load_golden
+
+CASES = [
+    ("fwd_c2_L2", "1H_HSQC_COSY_IR_MF_MW"),
+    ("fwd_c1_L2", "1H"),
+    ("fwd_all_L1", "1H_13C_HSQC_COSY_IR_MF_MW"),
+    ("fwd_ms_L1", "1H_13C_HSQC_COSY_IR_MF_MS_MW"),
+    ("fwd_nomf_L1", "1H_HSQC_COSY_IR"),
+    ("fwd_c2_L6", "1H_HSQC_COSY_IR_MF_MW"),
+]
+
+
+def _setup(g, mode):
+    nl = int(g["nl"])
+    cfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    sd = O.make_state_dict(cfg, int(g["wseed"]))
+    batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), mode)
+    return cfg, sd, batch
+
+
+@pytest.mark.parametrize("name,mode", CASES)
+def test_forward_matches_reference(name, mode):
+    g = load_golden(name)
+    cfg, sd, batch = _setup(g, mode)
+    with torch.no_grad():
+        loss, logits, fp, memory, mask = O.training_forward(sd, cfg, batch)
+        mem2, emb_src, mask2, fp2 = O.forward(sd, cfg, batch, None)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(fp.numpy(), g["fingerprint"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(mask.float().numpy(), g["mask"])
+    digest_close(digest(memory, 512), g["memory"], 1e-4, 2e-5)
+    digest_close(digest(emb_src, 512), g["embedding_src"], 1e-5, 1e-6)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("name,mode", CASES[:5])
+def test_gradients_match_reference(name, mode):
+    g = load_golden(name)
+    cfg, sd, batch = _setup(g, mode)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = O.training_forward(sd, cfg, batch)[0]
+    loss.backward()
+    nograd = set(str(k) for k in g["nograd"])
+    checked = 0
+    for k, p in sd.items():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        digest_close(digest(p.grad), g["grad/" + k], 2e-3, 1e-7)
+        checked += 1
+    assert checked > 50
+
+
+def test_adamw_two_steps():
+    g = load_golden("fwd_c2_L2")
+    cfg, sd, batch = _setup(g, "1H_HSQC_COSY_IR_MF_MW")
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+    losses = []
+    for step in (1, 2):
+        for p in params.values():
+            p.grad = None
+        loss = O.training_forward(params, cfg, batch)[0]
+        loss.backward()
+        losses.append(float(loss))
+        with torch.no_grad():
+            O.adamw_step(params, {k: p.grad for k, p in params.items()}, m, v, step, cfg["lr_pretraining"])
+    np.testing.assert_allclose(losses, g["step_losses"], atol=2e-5)
+    for k in g.files:
+        if k.startswith("post/"):
+            digest_close(digest(params[k[5:]]), g[k], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("name,mode", [("greedy_c2_L2", "1H_HSQC_COSY_IR_MF_MW"), ("greedy_c1_L2", "1H")])
+def test_greedy_tokens_identical(name, mode):
+    g = load_golden(name)
+    nl = int(g["nl"])
+    cfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    sd = O.make_state_dict(cfg, int(g["wseed"]), logit_gain=float(g["gain"]))
+    batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), mode)
+    with torch.no_grad():
+        memory, _, mask, fp = O.forward(sd, cfg, batch, None)
+        toks, probs, margins = O.greedy_sequence(sd, cfg, memory, mask)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    np.testing.assert_allclose(probs.numpy(), g["probs"], atol=1e-5)
+    itos = json.load(open(os.path.join(GOLDEN, "itos.json")))
+    assert O.tensor_to_smiles(toks, itos) == [str(s) for s in g["smiles"]]
+
+
+def test_tokenizer_and_padding():
+    t = json.load(open(os.path.join(GOLDEN, "text.json")))
+    stoi = json.load(open(os.path.join(GOLDEN, "stoi.json")))
+    itos = json.load(open(os.path.join(GOLDEN, "itos.json")))
+    stoi_MF = json.load(open(os.path.join(GOLDEN, "stoi_MF.json")))
+    for smi, toks, ids in zip(t["smiles"], t["tokens"], t["ids"]):
+        assert O.tokenize_smiles(smi) == toks
+        assert O.encode_smiles(stoi, smi) == ids
+    for f, ids in zip(t["formulas"], t["mf_ids"]):
+        assert O.encode_MF(stoi_MF, f) == ids
+    assert O.tensor_to_smiles(torch.tensor(t["decode_input"]), itos) == t["decoded"]
+    for key, (data, padded, mask) in t["pads"].items():
+        dims = int(key[3])
+        if dims == 1 and len(data) == 0:
+            continue
+        p, m = O.zero_pad(data, 64, dims)
+        np.testing.assert_allclose(p.numpy(), np.array(padded, np.float32), rtol=1e-6)
+        assert m.tolist() == mask

@@ -1,0 +1,30 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def digest(t, n=96):
+    """Same digest as oracle/make_golden.py: [sum, sum|x|, sum x^2] + n strided samples."""
+    a = np.asarray(t.detach().cpu().float().numpy() if hasattr(t, "detach") else t, dtype=np.float64).reshape(-1)
+    idx = np.linspace(0, a.size - 1, min(n, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
+
+
+def digest_close(got, want, rtol, atol):
+    """Compare two digests: the three moments relative to sum|x| / sum x^2, samples element-wise."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = max(want[1], 1e-30)
+    assert abs(got[0] - want[0]) <= rtol * scale + atol, ("sum", got[0], want[0])
+    assert abs(got[1] - want[1]) <= rtol * scale + atol, ("abs-sum", got[1], want[1])
+    assert abs(got[2] - want[2]) <= 2 * rtol * max(want[2], 1e-30) + atol, ("sq-sum", got[2], want[2])
+    # samples: tolerance relative to the tensor's own scale (largest sample), not to each element
+    span = float(np.abs(want[3:]).max()) if want.size > 3 else 0.0
+    np.testing.assert_allclose(got[3:], want[3:], rtol=rtol, atol=atol + rtol * span)
