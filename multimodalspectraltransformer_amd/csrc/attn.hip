@@ -1,0 +1,482 @@
+// Multi-head attention forward / backward, head_dim 8 or 32, for gfx950.
+//
+// One 64-lane wave owns a 32-row tile of one side ("owner" rows live on the MFMA
+// lane); the other side is streamed through LDS in 128-row chunks shared by the
+// workgroup's waves.  All products are v_mfma_f32_32x32x16_bf16:
+//   forward / dQ pass : owner = queries.  S^T = K Q^T puts a query's scores for 32
+//     keys into the 16 accumulator registers of the two lanes (l, l+32) of that query,
+//     so softmax statistics are lane-local plus one cross-half shuffle.  The
+//     probability registers are converted to bf16 in place and fed back as the B
+//     operand of O^T += V^T P^T (dQ^T += K^T dS^T); the A operand comes from a
+//     transposed LDS image whose k order matches the accumulator's row order.
+//   dK/dV pass        : owner = keys; S = Q K^T and dP = dO V^T are produced with the
+//     key on the lane, and P / dS feed dV^T += dO^T P and dK^T += Q^T dS.
+// head_dim 8 uses the same tiles with the contraction zero-padded to 16 (half of the
+// lanes supply zeros): the blocks are exp/VALU bound, the matrix pipe has slack.
+// Dropout on the attention probabilities is a counter hash of (b, h, q, key), so the
+// backward passes regenerate the forward's mask.
+#include "attn.h"
+
+namespace {
+
+constexpr int KC = 128;             // streamed rows per LDS chunk
+constexpr int TSTR = KC * 2 + 8;    // byte stride of a transposed-image row (== 8 mod 256)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int HD> struct Cfg {
+  static constexpr int KS = HD == 32 ? 2 : 1;       // contraction steps over head_dim
+  static constexpr int RM_BYTES = KC * HD * 2;      // row-major image
+  static constexpr int TR_BYTES = HD * TSTR;        // transposed image
+  static constexpr int OREGS = HD == 32 ? 16 : 4;   // valid accumulator registers of a d-major output
+};
+
+__device__ __forceinline__ int acc_row(int r16, int h) { return (r16 & 3) + 8 * (r16 >> 2) + 4 * h; }
+
+template <int HD>
+__device__ __forceinline__ int rm_off(int row, int ch) {
+  return HD == 32 ? row * 64 + ((ch ^ ((row >> 2) & 3)) << 4) : row * 16;
+}
+
+// Stage `nvalid` rows (zero-filled up to KC) of a [rows][HD] slice into a row-major
+// image and/or a transposed image.
+template <int HD, bool RM, bool TR>
+__device__ __forceinline__ void stage(unsigned char* rm, unsigned char* tr, const bf16* src, int ld, int nvalid,
+                                      int tid, int nthr) {
+  constexpr int CPR = HD / 8;
+  for (int c = tid; c < KC * CPR; c += nthr) {
+    int row = c / CPR, ch = c % CPR;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nvalid) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+    if (RM) *reinterpret_cast<uint4*>(rm + rm_off<HD>(row, ch)) = v;
+    if (TR) {
+      const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<unsigned short*>(tr + (ch * 8 + j) * TSTR + row * 2) = e[j];
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+  return z;
+}
+
+// A operand (32 rows x 16 k) from a row-major image: lane (r, h) takes row `row`, k = 16 s + 8 h ..
+template <int HD>
+__device__ __forceinline__ bf16x8 afrag_rm(const unsigned char* img, int row, int s, int h) {
+  if (HD == 32) return *reinterpret_cast<const bf16x8*>(img + rm_off<32>(row, 2 * s + h));
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 16);
+  return h == 0 ? v : zero8();
+}
+
+// A operand (rows = d, k = 16 streamed rows from c0 + 16 s) from a transposed image, with k in the
+// order of an accumulator's rows: element j of lane half h is streamed row 16 s + 8 (j>>2) + 4 h + (j&3).
+template <int HD>
+__device__ __forceinline__ bf16x8 afrag_tr(const unsigned char* img, int c0, int s, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int d = HD == 32 ? r : (r & 7);
+  const unsigned char* p = img + d * TSTR + (c0 + 16 * s + 4 * h) * 2;
+  s16x4 lo = *reinterpret_cast<const s16x4*>(p);
+  s16x4 hi = *reinterpret_cast<const s16x4*>(p + 16);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  bf16x8 o = __builtin_bit_cast(bf16x8, v);
+  if (HD == 8 && r >= 8) o = zero8();
+  return o;
+}
+
+// B operand of an owner row kept in registers: lane (r, h) holds row r, k = 16 s + 8 h ..
+template <int HD>
+__device__ __forceinline__ void load_owner(bf16x8 (&f)[Cfg<HD>::KS], const bf16* rowptr, int h, bool valid) {
+  if (HD == 32) {
+#pragma unroll
+    for (int s = 0; s < Cfg<HD>::KS; ++s)
+      f[s] = valid ? *reinterpret_cast<const bf16x8*>(rowptr + 16 * s + 8 * h) : zero8();
+  } else {
+    f[0] = (valid && h == 0) ? *reinterpret_cast<const bf16x8*>(rowptr) : zero8();
+  }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+  return o;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// store a d-major accumulator (lane = owner row, registers = d) as a bf16 row slice
+template <int HD>
+__device__ __forceinline__ void store_rows(bf16* rowptr, const f32x16& acc, float mul, int h) {
+  constexpr int G = HD == 32 ? 4 : 1;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[4 * g + j] * mul);
+    *reinterpret_cast<bf16x4*>(rowptr + 8 * g + 4 * h) = o;
+  }
+}
+
+struct BlockCoord { int g, b, hh, blk; };
+__device__ __forceinline__ BlockCoord locate(const AttnBatch& batch) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < ATTN_MAX_GROUPS; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].block_begin) g = i;
+  const AttnProb& pr = batch.p[g];
+  int local = blockIdx.x - pr.block_begin;
+  int bh = local / pr.blocks_per_bh;
+  BlockCoord c;
+  c.g = g;
+  c.blk = local % pr.blocks_per_bh;
+  c.b = bh / pr.H;
+  c.hh = bh % pr.H;
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward (BWD = false) and dQ pass (BWD = true): owner = queries
+// ------------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL, bool BWD>
+__global__ void attn_q_kernel(const AttnBatch batch) {
+  typedef Cfg<HD> C;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::RM_BYTES * (BWD ? 2 : 1) + C::TR_BYTES + KC * 4];
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + C::RM_BYTES;                    // BWD only (row-major V)
+  unsigned char* Timg = smem + C::RM_BYTES * (BWD ? 2 : 1);    // fwd: V^T, bwd: K^T
+  float* bias = reinterpret_cast<float*>(Timg + C::TR_BYTES);
+
+  const BlockCoord bc = locate(batch);
+  const AttnProb& pr = batch.p[bc.g];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = bc.b, hh = bc.hh, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const int q0 = (bc.blk * nw + wave) * 32;
+  const bool active = q0 < Tq;
+  const int q = q0 + r;
+  const bool qvalid = active && q < Tq;
+  const float scale = rsqrtf((float)HD);
+  const float scale2 = scale * LOG2E;
+  const uint32_t thr = drop_threshold(batch.drop_p);
+  const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
+  const bool dropping = batch.drop_p > 0.f;
+  const uint32_t Skp = (uint32_t)((Sk + 1) & ~1);
+  const uint32_t rowbase = (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)) * Skp;
+
+  bf16x8 qf[C::KS], dof[C::KS];
+  load_owner<HD>(qf, pr.Q + (size_t)(b * Tq + (qvalid ? q : 0)) * pr.ldq + hh * HD, h, qvalid);
+  float lse2 = 0.f, delta = 0.f;
+  if (BWD) {
+    load_owner<HD>(dof, pr.dO + (size_t)(b * Tq + (qvalid ? q : 0)) * pr.lddo + hh * HD, h, qvalid);
+    bf16x8 of[C::KS];
+    load_owner<HD>(of, pr.O + (size_t)(b * Tq + (qvalid ? q : 0)) * pr.ldo + hh * HD, h, qvalid);
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
+    delta += __shfl_xor(delta, 32);
+    if (qvalid) {
+      lse2 = pr.lse[(size_t)(b * H + hh) * Tq + q];
+      if (h == 0) pr.delta[(size_t)(b * H + hh) * Tq + q] = delta;
+    }
+  }
+
+  float m = NEG_BIG, l = 0.f;
+  f32x16 oacc = zero16();
+
+  for (int c0 = 0; c0 < Sk; c0 += KC) {
+    const int nvalid = min(KC, Sk - c0);
+    __syncthreads();
+    const bf16* ksrc = pr.K + (size_t)(b * Sk + c0) * pr.ldk + hh * HD;
+    const bf16* vsrc = pr.V + (size_t)(b * Sk + c0) * pr.ldv + hh * HD;
+    if (!BWD) {
+      stage<HD, true, false>(Kimg, nullptr, ksrc, pr.ldk, nvalid, tid, nthr);
+      stage<HD, false, true>(nullptr, Timg, vsrc, pr.ldv, nvalid, tid, nthr);
+    } else {
+      stage<HD, true, true>(Kimg, Timg, ksrc, pr.ldk, nvalid, tid, nthr);
+      stage<HD, true, false>(Vimg, nullptr, vsrc, pr.ldv, nvalid, tid, nthr);
+    }
+    for (int i = tid; i < KC; i += nthr) {
+      float bv = -INFINITY;
+      if (i < nvalid) bv = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + i] * LOG2E : 0.f;
+      bias[i] = bv;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int ntile = (nvalid + 31) >> 5;
+    for (int t = 0; t < ntile; ++t) {
+      const int lk0 = t * 32;
+      if (CAUSAL && c0 + lk0 > q0 + 31) break;
+      f32x16 sacc = zero16();
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s)
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Kimg, lk0 + r, s, h), qf[s], sacc, 0, 0, 0);
+      float sv[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 bb = *reinterpret_cast<const f32x4*>(bias + lk0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = sacc[4 * g4 + j] * scale2 + bb[j];
+          if (CAUSAL && (c0 + lk0 + 8 * g4 + 4 * h + j) > q) v = -INFINITY;
+          sv[4 * g4 + j] = v;
+        }
+      }
+      float pv[16];
+      if (!BWD) {
+        float tmax = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sv[i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { pv[i] = __builtin_amdgcn_exp2f(sv[i] - mn); ps += pv[i]; }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < C::OREGS; ++i) oacc[i] *= alpha;
+        if (dropping) {
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            uint32_t idx = rowbase + (uint32_t)(c0 + lk0 + acc_row(i, h));
+            uint32_t hb = drop_bits(pr.seed, idx >> 1);
+            pv[i] = ((hb & 0xFFFFu) >= thr) ? pv[i] * dscale : 0.f;
+            pv[i + 1] = ((hb >> 16) >= thr) ? pv[i + 1] * dscale : 0.f;
+          }
+        }
+      } else {
+        f32x16 dpacc = zero16();
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Vimg, lk0 + r, s, h), dof[s], dpacc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          float p0 = __builtin_amdgcn_exp2f(sv[i] - lse2), p1 = __builtin_amdgcn_exp2f(sv[i + 1] - lse2);
+          float d0 = dpacc[i], d1 = dpacc[i + 1];
+          if (dropping) {
+            uint32_t idx = rowbase + (uint32_t)(c0 + lk0 + acc_row(i, h));
+            uint32_t hb = drop_bits(pr.seed, idx >> 1);
+            d0 = ((hb & 0xFFFFu) >= thr) ? d0 * dscale : 0.f;
+            d1 = ((hb >> 16) >= thr) ? d1 * dscale : 0.f;
+          }
+          pv[i] = p0 * (d0 - delta) * scale;
+          pv[i + 1] = p1 * (d1 - delta) * scale;
+        }
+      }
+      const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 0, lane), pf0, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 1, lane), pf1, oacc, 0, 0, 0);
+    }
+  }
+  if (!qvalid) return;
+  if (!BWD) {
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    store_rows<HD>(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, oacc, inv, h);
+    if (h == 0) pr.lse[(size_t)(b * H + hh) * Tq + q] = m + __builtin_amdgcn_logf(l);
+  } else {
+    store_rows<HD>(pr.dQ + (size_t)(b * Tq + q) * pr.lddq + hh * HD, oacc, 1.0f, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dK / dV pass: owner = keys, queries streamed
+// ------------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL>
+__global__ void attn_kv_kernel(const AttnBatch batch) {
+  typedef Cfg<HD> C;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 2 * KC * 4];
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = smem + C::RM_BYTES;
+  unsigned char* Qt = smem + 2 * C::RM_BYTES;
+  unsigned char* Dt = Qt + C::TR_BYTES;
+  float* lse_s = reinterpret_cast<float*>(Dt + C::TR_BYTES);
+  float* del_s = lse_s + KC;
+
+  const BlockCoord bc = locate(batch);
+  const AttnProb& pr = batch.p[bc.g];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = bc.b, hh = bc.hh, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const int k0 = (bc.blk * nw + wave) * 32;
+  const bool active = k0 < Sk;
+  const int key = k0 + r;
+  const bool kvalid = active && key < Sk;
+  const float scale = rsqrtf((float)HD);
+  const float scale2 = scale * LOG2E;
+  const uint32_t thr = drop_threshold(batch.drop_p);
+  const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
+  const bool dropping = batch.drop_p > 0.f;
+  const uint32_t Skp = (uint32_t)((Sk + 1) & ~1);
+
+  bf16x8 kf[C::KS], vf[C::KS];
+  load_owner<HD>(kf, pr.K + (size_t)(b * Sk + (kvalid ? key : 0)) * pr.ldk + hh * HD, h, kvalid);
+  load_owner<HD>(vf, pr.V + (size_t)(b * Sk + (kvalid ? key : 0)) * pr.ldv + hh * HD, h, kvalid);
+  float bias2 = -INFINITY;
+  if (kvalid) bias2 = pr.kbias ? pr.kbias[(size_t)b * Sk + key] * LOG2E : 0.f;
+
+  f32x16 dkacc = zero16(), dvacc = zero16();
+
+  for (int c0 = 0; c0 < Tq; c0 += KC) {
+    const int nvalid = min(KC, Tq - c0);
+    __syncthreads();
+    stage<HD, true, true>(Qimg, Qt, pr.Q + (size_t)(b * Tq + c0) * pr.ldq + hh * HD, pr.ldq, nvalid, tid, nthr);
+    stage<HD, true, true>(Dimg, Dt, pr.dO + (size_t)(b * Tq + c0) * pr.lddo + hh * HD, pr.lddo, nvalid, tid, nthr);
+    for (int i = tid; i < KC; i += nthr) {
+      float lv = 1.0e30f, dv = 0.f;
+      if (i < nvalid) {
+        lv = pr.lse[(size_t)(b * H + hh) * Tq + c0 + i];
+        dv = pr.delta[(size_t)(b * H + hh) * Tq + c0 + i];
+      }
+      lse_s[i] = lv;
+      del_s[i] = dv;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int ntile = (nvalid + 31) >> 5;
+    for (int t = 0; t < ntile; ++t) {
+      const int lq0 = t * 32;
+      if (CAUSAL && c0 + lq0 + 31 < k0) continue;  // every query of the tile precedes every key
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Qimg, lq0 + r, s, h), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Dimg, lq0 + r, s, h), vf[s], dpacc, 0, 0, 0);
+      }
+      float pd[16], ds[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 ll = *reinterpret_cast<const f32x4*>(lse_s + lq0 + 8 * g4 + 4 * h);
+        f32x4 dd = *reinterpret_cast<const f32x4*>(del_s + lq0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g4 + j;
+          const int qg = c0 + lq0 + 8 * g4 + 4 * h + j;
+          float v = sacc[i] * scale2 + bias2;
+          if (CAUSAL && key > qg) v = -INFINITY;
+          float p = __builtin_amdgcn_exp2f(v - ll[j]);
+          float d = dpacc[i];
+          float pk = p;
+          if (dropping) {
+            uint32_t idx = (uint32_t)((b * H + hh) * Tq + qg) * Skp + (uint32_t)key;
+            uint32_t hb = drop_bits(pr.seed, idx >> 1);
+            uint32_t bits = (key & 1) ? (hb >> 16) : (hb & 0xFFFFu);
+            bool keep = bits >= thr;
+            d = keep ? d * dscale : 0.f;
+            pk = keep ? p * dscale : 0.f;
+          }
+          pd[i] = pk;
+          ds[i] = p * (d - dd[j]) * scale;
+        }
+      }
+      const bf16x8 pf0 = pack8(pd), pf1 = pack8(pd + 8), sf0 = pack8(ds), sf1 = pack8(ds + 8);
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 0, lane), pf0, dvacc, 0, 0, 0);
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 1, lane), pf1, dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 0, lane), sf0, dkacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 1, lane), sf1, dkacc, 0, 0, 0);
+    }
+  }
+  if (!kvalid) return;
+  store_rows<HD>(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dkacc, 1.0f, h);
+  store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
+}
+
+// waves per workgroup and workgroups per (batch, head) for `rows` owner rows
+void plan(const AttnBatch& b, bool owner_is_key, int& nw, int (&bpb)[ATTN_MAX_GROUPS]) {
+  nw = 1;
+  for (int i = 0; i < b.n; ++i) {
+    int rows = owner_is_key ? b.p[i].Sk : b.p[i].Tq;
+    int tiles = (rows + 31) / 32;
+    int nblk = (tiles + 7) / 8;
+    int w = (tiles + nblk - 1) / nblk;
+    if (w > nw) nw = w;
+  }
+  for (int i = 0; i < b.n; ++i) {
+    int rows = owner_is_key ? b.p[i].Sk : b.p[i].Tq;
+    int tiles = (rows + 31) / 32;
+    bpb[i] = (tiles + nw - 1) / nw;
+  }
+}
+
+int check(const AttnBatch& b) {
+  if (b.n < 1 || b.n > ATTN_MAX_GROUPS) return MMST_ERR_ARG;
+  if (b.hd != 8 && b.hd != 32) return MMST_ERR_ARG;
+  for (int i = 0; i < b.n; ++i) {
+    const AttnProb& p = b.p[i];
+    if (p.B < 1 || p.H < 1 || p.Tq < 1 || p.Sk < 1) return MMST_ERR_ARG;
+    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return MMST_ERR_ARG;
+  }
+  return MMST_OK;
+}
+
+template <bool BWD>
+int launch_q(AttnBatch& b, hipStream_t stream) {
+  int nw, bpb[ATTN_MAX_GROUPS];
+  plan(b, false, nw, bpb);
+  int total = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.p[i].blocks_per_bh = bpb[i];
+    b.p[i].block_begin = total;
+    total += bpb[i] * b.p[i].B * b.p[i].H;
+  }
+  dim3 grid(total), block(64 * nw);
+  if (b.hd == 32) {
+    if (b.causal) hipLaunchKernelGGL((attn_q_kernel<32, true, BWD>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((attn_q_kernel<32, false, BWD>), grid, block, 0, stream, b);
+  } else {
+    if (b.causal) hipLaunchKernelGGL((attn_q_kernel<8, true, BWD>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((attn_q_kernel<8, false, BWD>), grid, block, 0, stream, b);
+  }
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+}  // namespace
+
+int launch_attn_fwd(AttnBatch& b, hipStream_t stream) {
+  int rc = check(b);
+  if (rc) return rc;
+  return launch_q<false>(b, stream);
+}
+
+int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {
+  int rc = check(b);
+  if (rc) return rc;
+  for (int i = 0; i < b.n; ++i) {
+    const AttnProb& p = b.p[i];
+    if ((p.lddo & 7) || (p.lddq & 3) || (p.lddk & 3) || (p.lddv & 3)) return MMST_ERR_ARG;
+  }
+  rc = launch_q<true>(b, stream);
+  if (rc) return rc;
+  int nw, bpb[ATTN_MAX_GROUPS];
+  plan(b, true, nw, bpb);
+  int total = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.p[i].blocks_per_bh = bpb[i];
+    b.p[i].block_begin = total;
+    total += bpb[i] * b.p[i].B * b.p[i].H;
+  }
+  dim3 grid(total), block(64 * nw);
+  if (b.hd == 32) {
+    if (b.causal) hipLaunchKernelGGL((attn_kv_kernel<32, true>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((attn_kv_kernel<32, false>), grid, block, 0, stream, b);
+  } else {
+    if (b.causal) hipLaunchKernelGGL((attn_kv_kernel<8, true>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((attn_kv_kernel<8, false>), grid, block, 0, stream, b);
+  }
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}

@@ -1,0 +1,60 @@
+// Shared device helpers for the gfx950 kernels of the spectral-transformer path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDS_AS __attribute__((address_space(3)))
+
+#define MMST_OK 0
+#define MMST_ERR_ARG (-1)
+#define MMST_ERR_LAUNCH (-2)
+
+#define MMST_CHECK_LAUNCH()                         \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return MMST_ERR_LAUNCH;  \
+  } while (0)
+
+// Counter-based dropout: one 32-bit mix per PAIR of elements, 16 bits each.
+// keep(idx) == true with probability 1 - thr/65536.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t seed, uint32_t pair_idx) {
+  return mix32(pair_idx * 0x9E3779B9U + seed);
+}
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr) {
+  uint32_t h = drop_bits(seed, idx >> 1);
+  uint32_t b = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return b >= thr;
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  return (uint32_t)(p * 65536.0f + 0.5f);
+}
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

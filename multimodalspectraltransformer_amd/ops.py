@@ -1,0 +1,70 @@
+"""Thin Python wrappers that fill the C structs of libmmst.so from torch tensors.
+
+Every function enqueues HIP kernels on torch's current stream and returns
+immediately; nothing here computes on the host.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", "dgamma", "dbeta", "dbias")
+
+
+def gemm_batch(groups):
+    """groups: list of dicts with GemmProb field names; tensors for pointer fields."""
+    if not 1 <= len(groups) <= L.MAX_GROUPS:
+        raise L.MMSTError("gemm: 1..%d groups" % L.MAX_GROUPS)
+    b = L.GemmBatch()
+    b.n = len(groups)
+    for i, g in enumerate(groups):
+        p = b.p[i]
+        for k, v in g.items():
+            if k in _PTR_FIELDS:
+                setattr(p, k, L.ptr(v) if isinstance(v, torch.Tensor) else v)
+            else:
+                setattr(p, k, v)
+    return b
+
+
+def gemm_launch(batch, epi, pt=False, qt=False):
+    L.check(L.lib().mmst_gemm(C.byref(batch), epi, int(pt), int(qt), L.stream_ptr()), "mmst_gemm")
+
+
+def gemm(groups, epi, pt=False, qt=False):
+    gemm_launch(gemm_batch(groups), epi, pt, qt)
+
+
+_APTR = ("Q", "K", "V", "kbias", "O", "lse", "dO", "delta", "dQ", "dK", "dV")
+
+
+def attn_batch(groups, hd, causal=False, drop_p=0.0):
+    if not 1 <= len(groups) <= L.MAX_GROUPS:
+        raise L.MMSTError("attn: 1..%d groups" % L.MAX_GROUPS)
+    b = L.AttnBatch()
+    b.n = len(groups)
+    b.hd = hd
+    b.causal = int(causal)
+    b.drop_p = float(drop_p)
+    for i, g in enumerate(groups):
+        p = b.p[i]
+        for k, v in g.items():
+            if k in _APTR:
+                setattr(p, k, v if (v is None or isinstance(v, int)) else L.ptr(v))
+            else:
+                setattr(p, k, v)
+    return b
+
+
+def attn_fwd_launch(batch):
+    L.check(L.lib().mmst_attn_fwd(C.byref(batch), L.stream_ptr()), "mmst_attn_fwd")
+
+
+def attn_bwd_launch(batch):
+    L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
+
+
+def eptr(t, offset_elems):
+    """Device address of element `offset_elems` of tensor t."""
+    return t.data_ptr() + offset_elems * t.element_size()

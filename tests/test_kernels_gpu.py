@@ -1,0 +1,273 @@
+"""Kernel-level parity on the GPU: every GEMM operand mode / epilogue and the attention
+forward/backward kernels against fp32 torch math on the same bf16-rounded inputs.
+
+Tolerances: inputs are rounded to bf16 first, so the only differences are the bf16
+rounding of stored outputs (rel 2^-8) and fp32 summation order."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multimodalspectraltransformer_amd import _lib as L
+    from multimodalspectraltransformer_amd import ops
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def close(got, want, rtol=2e-2, atol=2e-2):
+    got = got.float()
+    want = want.float()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= atol * max(ref, 1e-6) + 1e-6, f"max err {err} vs ref scale {ref}"
+    # relative Frobenius error is a much sharper check than max-abs
+    fro = ((got - want).norm() / (want.norm() + 1e-3)).item()
+    assert fro <= rtol, f"relative Frobenius error {fro}"
+
+
+# --------------------------------------------------------------------------- dropout hash (host copy)
+def mix32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def keep_mask(seed, idx, p):
+    """numpy restatement of drop_keep() in csrc/common.h"""
+    thr = int(p * 65536.0 + 0.5)
+    idx = idx.astype(np.uint64)
+    h = mix32(((idx >> np.uint64(1)) * np.uint64(0x9E3779B9) + np.uint64(seed)) & np.uint64(0xFFFFFFFF))
+    bits = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return bits >= thr
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (128, 128, 2048), (77, 64, 128), (1000, 2048, 128), (64, 128, 1024)])
+def test_gemm_bias_relu(M, N, K):
+    x, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.1, seed=2)), rnd(N, seed=3)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm([dict(P=x, Q=w, C=out, bias=b, ldp=K, ldq=K, ldc=N, Pn=M, Qn=N, K=K, flags=L.GF_RELU)], L.EPI_BIAS)
+    close(out, torch.relu(x.float() @ w.float().t() + b))
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    r = bf(rnd(M, N, seed=4))
+    ops.gemm([dict(P=x, Q=w, C=out32, R=r, ldr=N, ldp=K, ldq=K, ldc=N, Pn=M, Qn=N, K=K, flags=L.GF_OUT_F32)],
+             L.EPI_BIAS)
+    close(out32, x.float() @ w.float().t() + r.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_grouped():
+    groups, wants, outs = [], [], []
+    for i, (M, N, K) in enumerate([(129 * 3, 384, 128), (66 * 3, 384, 128), (200, 128, 128)]):
+        x, w, b = bf(rnd(M, K, seed=10 + i)), bf(rnd(N, K, scale=0.1, seed=20 + i)), rnd(N, seed=30 + i)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        groups.append(dict(P=x, Q=w, C=out, bias=b, ldp=K, ldq=K, ldc=N, Pn=M, Qn=N, K=K))
+        wants.append(x.float() @ w.float().t() + b)
+        outs.append(out)
+    ops.gemm(groups, L.EPI_BIAS)
+    for o, w_ in zip(outs, wants):
+        close(o, w_)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (513, 2048, 128), (100, 128, 2048), (90, 64, 128)])
+def test_gemm_dx(M, N, K):
+    """dX[M,K] = dY[M,N] @ W[N,K]: W is the contraction-major Q operand."""
+    dy, w = bf(rnd(M, N, seed=1)), bf(rnd(N, K, scale=0.1, seed=2))
+    r = bf(rnd(M, K, seed=3))
+    out = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    ops.gemm([dict(P=dy, Q=w, C=out, R=r, ldr=K, ldp=N, ldq=K, ldc=K, Pn=M, Qn=K, K=N)], L.EPI_BIAS, qt=True)
+    close(out, dy.float() @ w.float() + r.float())
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 384, 128, 1), (1000, 2048, 128, 4), (777, 128, 2048, 3), (70, 64, 128, 2)])
+def test_gemm_dw(M, N, K, split):
+    """dW[N,K] += dY[M,N]^T @ X[M,K], db[N] += colsum(dY): both operands contraction-major."""
+    dy, x = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
+    dw = torch.zeros(N, K, dtype=torch.float32, device=DEV)
+    db = torch.zeros(N, dtype=torch.float32, device=DEV)
+    ops.gemm([dict(P=dy, Q=x, C=dw, dbias=db, ldp=N, ldq=K, ldc=K, Pn=N, Qn=K, K=M, ksplit=split)],
+             L.EPI_ATOMIC, pt=True, qt=True)
+    close(dw, dy.float().t() @ x.float(), rtol=1e-3, atol=1e-3)
+    close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_drelu():
+    M, N, K = 300, 2048, 128
+    dy, w = bf(rnd(M, K, seed=1)), bf(rnd(K, N, scale=0.1, seed=2))   # dH = dY[M,128] @ W2[128,2048]
+    h = bf(torch.relu(rnd(M, N, seed=3)))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm([dict(P=dy, Q=w, C=out, R=h, ldr=N, ldp=K, ldq=N, ldc=N, Pn=M, Qn=N, K=K, drop_p=0.1)],
+             L.EPI_DRELU, qt=True)
+    want = (dy.float() @ w.float()) * (h.float() > 0) / 0.9
+    close(out, want)
+
+
+@pytest.mark.parametrize("M,K", [(300, 128), (129, 2048)])
+def test_gemm_layernorm_fwd_bwd(M, K):
+    x, w, b = bf(rnd(M, K, seed=1)), bf(rnd(128, K, scale=0.1, seed=2)), rnd(128, seed=3)
+    r = bf(rnd(M, 128, seed=4))
+    gam, bet = 1 + 0.1 * rnd(128, seed=5), 0.1 * rnd(128, seed=6)
+    y = torch.empty(M, 128, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty_like(y)
+    st = torch.empty(M, 2, dtype=torch.float32, device=DEV)
+    ops.gemm([dict(P=x, Q=w, C=y, bias=b, R=r, ldr=128, gamma=gam, beta=bet, Z=z, stats=st,
+                   ldp=K, ldq=K, ldc=128, Pn=M, Qn=128, K=K)], L.EPI_LN)
+    zref = (x.float() @ w.float().t() + b + r.float()).requires_grad_(True)
+    gref = gam.clone().requires_grad_(True)
+    bref = bet.clone().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(zref, (128,), gref, bref, 1e-5)
+    close(z, zref.detach())
+    close(y, yref.detach())
+    close(st[:, 0], zref.detach().mean(1), rtol=1e-3, atol=1e-3)
+    # backward: dy = dY2 @ W[Kb,128] + Rg ; here take the K=0 path (dy = R) and a GEMM path
+    dy = bf(rnd(M, 128, seed=7))
+    yref.backward(dy.float())
+    # recompute reference with the kernel's bf16 z to isolate the backward arithmetic
+    dz = torch.empty(M, 128, dtype=torch.bfloat16, device=DEV)
+    dzd = torch.empty_like(dz)
+    dg = torch.zeros(128, device=DEV)
+    dbt = torch.zeros(128, device=DEV)
+    ops.gemm([dict(C=dz, C2=dzd, R=dy, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=dbt,
+                   ldp=8, ldq=8, ldc=128, Pn=M, Qn=128, K=0, drop_p=0.0)], L.EPI_LNBWD)
+    close(dz, zref.grad, rtol=3e-2, atol=3e-2)
+    close(dzd, zref.grad, rtol=3e-2, atol=3e-2)
+    close(dg, gref.grad, rtol=2e-2, atol=2e-2)
+    close(dbt, bref.grad, rtol=1e-2, atol=1e-2)
+    # with a GEMM in front: dy = dh[M,256] @ W1[256,128] + Rg
+    dh, w1 = bf(rnd(M, 256, seed=8)), bf(rnd(256, 128, scale=0.1, seed=9))
+    dy2 = (dh.float() @ w1.float() + dy.float())
+    zref2 = z.float().detach().requires_grad_(True)
+    torch.nn.functional.layer_norm(zref2, (128,), gam, bet, 1e-5).backward(dy2)
+    dg.zero_()
+    dbt.zero_()
+    ops.gemm([dict(P=dh, Q=w1, C=dz, C2=None, R=dy, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=dbt,
+                   ldp=256, ldq=128, ldc=128, Pn=M, Qn=128, K=256)], L.EPI_LNBWD, qt=True)
+    close(dz, zref2.grad, rtol=3e-2, atol=3e-2)
+
+
+def test_gemm_dropout_consistency():
+    """Forward dropout (LN epilogue) and the regenerated mask in the LN-backward epilogue agree with
+    the host restatement of the hash, and the keep rate is 1-p."""
+    M, K, p, seed = 512, 128, 0.1, 1234
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(128, K, scale=0.1, seed=2))
+    y = torch.empty(M, 128, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty_like(y)
+    st = torch.empty(M, 2, device=DEV)
+    gam, bet = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    ops.gemm([dict(P=x, Q=w, C=y, gamma=gam, beta=bet, Z=z, stats=st, ldp=K, ldq=K, ldc=128,
+                   Pn=M, Qn=128, K=K, drop_p=p, seed=seed)], L.EPI_LN)
+    keep = torch.from_numpy(keep_mask(seed, np.arange(M * 128), p).reshape(M, 128)).to(DEV)
+    assert abs(keep.float().mean().item() - 0.9) < 0.01
+    want = (x.float() @ w.float().t()) * keep / (1 - p)
+    close(z, want)
+    dz = torch.empty_like(y)
+    dzd = torch.empty_like(y)
+    dy = bf(rnd(M, 128, seed=3))
+    ops.gemm([dict(C=dz, C2=dzd, R=dy, ldr=128, gamma=gam, Z=z, stats=st, ldp=8, ldq=8, ldc=128,
+                   Pn=M, Qn=128, K=0, drop_p=p, seed=seed)], L.EPI_LNBWD)
+    close(dzd, dz.float() * keep / (1 - p), rtol=1e-2, atol=1e-2)
+
+
+# --------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, bias, causal, hd, keep=None, p=0.0):
+    """q (B,T,H,hd) fp32 etc.  Returns O (B,T,H,hd)."""
+    s = torch.einsum("bthd,bshd->bhts", q, k) / math.sqrt(hd)
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    if causal:
+        T, S = s.shape[-2:]
+        s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device), diagonal=1)
+    a = torch.softmax(s, dim=-1)
+    if keep is not None:
+        a = a * keep / (1 - p)
+    return torch.einsum("bhts,bshd->bthd", a, v)
+
+
+def run_attn(B, H, T, S, hd, causal, use_bias, p=0.0, seed=77, self_attn=True):
+    d = H * hd
+    if self_attn:
+        qkv = bf(rnd(B * T, 3 * d, seed=1))
+        Q, K_, V = qkv, qkv, qkv
+        qo, ko, vo, ldq, ldk = 0, d, 2 * d, 3 * d, 3 * d
+    else:
+        Q = bf(rnd(B * T, d, seed=1))
+        K_ = bf(rnd(B * S, 2 * d, seed=2))
+        V = K_
+        qo, ko, vo, ldq, ldk = 0, 0, d, d, 2 * d
+    bias = None
+    if use_bias:
+        bias = (torch.rand(B, S, generator=torch.Generator().manual_seed(5)) < 0.3).float().to(DEV)
+        bias[:, S // 2:S // 2 + 3] = float("-inf")
+    O = torch.zeros(B * T, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, H, T, device=DEV)
+    grp = dict(Q=ops.eptr(Q, qo), K=ops.eptr(K_, ko), V=ops.eptr(V, vo), kbias=bias, O=O, lse=lse,
+               ldq=ldq, ldk=ldk, ldv=ldk, ldo=d, B=B, H=H, Tq=T, Sk=S, seed=seed)
+    ops.attn_fwd_launch(ops.attn_batch([grp], hd, causal, p))
+    qf = Q.float()[:, qo:qo + d].reshape(B, T, H, hd).clone().requires_grad_(True)
+    kf = K_.float()[:, ko:ko + d].reshape(B, S, H, hd).clone().requires_grad_(True)
+    vf = V.float()[:, vo:vo + d].reshape(B, S, H, hd).clone().requires_grad_(True)
+    keep = None
+    if p > 0:
+        Skp = (S + 1) & ~1
+        b_, h_, t_, s_ = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(S), indexing="ij")
+        idx = ((b_ * H + h_) * T + t_) * Skp + s_
+        keep = torch.from_numpy(keep_mask(seed, idx.reshape(-1), p).reshape(B, H, T, S)).to(DEV)
+    ref = attn_ref(qf, kf, vf, bias, causal, hd, keep, p)
+    close(O.reshape(B, T, H, hd), ref.detach())
+    # backward
+    dO = bf(rnd(B * T, d, seed=9))
+    ref.backward(dO.float().reshape(B, T, H, hd))
+    delta = torch.zeros(B, H, T, device=DEV)
+    if self_attn:
+        dqkv = torch.zeros(B * T, 3 * d, dtype=torch.bfloat16, device=DEV)
+        dQ, dK, dV, lq, lk = ops.eptr(dqkv, 0), ops.eptr(dqkv, d), ops.eptr(dqkv, 2 * d), 3 * d, 3 * d
+    else:
+        dq_t = torch.zeros(B * T, d, dtype=torch.bfloat16, device=DEV)
+        dkv_t = torch.zeros(B * S, 2 * d, dtype=torch.bfloat16, device=DEV)
+        dQ, dK, dV, lq, lk = ops.eptr(dq_t, 0), ops.eptr(dkv_t, 0), ops.eptr(dkv_t, d), d, 2 * d
+    grp.update(dO=dO, delta=delta, dQ=dQ, dK=dK, dV=dV, lddo=d, lddq=lq, lddk=lk, lddv=lk)
+    ops.attn_bwd_launch(ops.attn_batch([grp], hd, causal, p))
+    if self_attn:
+        gq, gk, gv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+    else:
+        gq, gk, gv = dq_t, dkv_t[:, :d], dkv_t[:, d:]
+    close(gq.reshape(B, T, H, hd), qf.grad, rtol=3e-2, atol=3e-2)
+    close(gk.reshape(B, S, H, hd), kf.grad, rtol=3e-2, atol=3e-2)
+    close(gv.reshape(B, S, H, hd), vf.grad, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("B,H,S,hd", [(2, 16, 129, 8), (3, 16, 66, 8), (2, 4, 582, 32), (1, 4, 453, 32),
+                                       (2, 16, 193, 8), (1, 4, 902, 32)])
+def test_attn_self(B, H, S, hd):
+    run_attn(B, H, S, S, hd, causal=False, use_bias=True)
+
+
+@pytest.mark.parametrize("T", [1, 5, 63, 128])
+def test_attn_causal(T):
+    run_attn(2, 16, T, T, 8, causal=True, use_bias=False)
+
+
+@pytest.mark.parametrize("T,S", [(63, 582), (1, 453), (128, 902)])
+def test_attn_cross(T, S):
+    run_attn(2, 16, T, S, 8, causal=False, use_bias=True, self_attn=False)
+
+
+@pytest.mark.parametrize("hd,H,S", [(8, 16, 129), (32, 4, 300)])
+def test_attn_dropout(hd, H, S):
+    run_attn(2, H, S, S, hd, causal=False, use_bias=True, p=0.1)
