@@ -1,0 +1,192 @@
+/* libmmst.so -- C ABI of the MI355X (gfx950) spectral-transformer hot path.
+ *
+ * Every entry point: plain C, raw DEVICE pointers + sizes + a hipStream_t passed as void*,
+ * returns 0 on success or a negative error code (never throws), allocates nothing, keeps no
+ * global state, and only ENQUEUES kernels on the given stream (graph-capture safe).
+ *
+ * The reference (a PyTorch nn.Module, no FFI of its own) is replaced at the level of the
+ * torch.nn calls it makes; each function cites the reference call site it stands in for
+ * (paths relative to the reference checkout, utils_MMT/models_MMT_v15_4.py unless noted).
+ *
+ * Conventions
+ *   - activations: bf16, batch-first token rows, row (b, s) at index b*S + s, 128 columns
+ *   - weights:     bf16 copies of the fp32 master parameters, torch layout [out][in]
+ *   - biases / LayerNorm affine / gradients of parameters: fp32
+ *   - parameter gradients are ACCUMULATED (atomically); the caller zeroes them per step
+ *   - key-padding masks are additive fp32 biases [B][S] (0/1 reference-style, -inf, or any value)
+ *   - dropout: counter-based hash of (seed, element index); a layer uses seeds seed .. seed+7
+ *     for its dropout sites; backward must be given the same seed and drop_p as forward
+ */
+#ifndef MMST_H
+#define MMST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMST_D 128        /* hidden_size (hard-wired in the reference's blank-modality branch, :852) */
+#define MMST_FF 2048      /* torch default dim_feedforward (config.forward_expansion is never read) */
+#define MMST_MAX_GROUPS 6 /* sequences (modalities) processed by one grouped launch */
+
+/* ---- one post-norm encoder layer == nn.TransformerEncoderLayer(d_model=128, nhead) (:510-533) ---- */
+typedef struct {
+  const void* w_qkv; const float* b_qkv;   /* self_attn.in_proj_weight [384][128], in_proj_bias */
+  const void* w_o;   const float* b_o;     /* self_attn.out_proj */
+  const void* w_1;   const float* b_1;     /* linear1 [2048][128] */
+  const void* w_2;   const float* b_2;     /* linear2 [128][2048] */
+  const float* g1; const float* be1;       /* norm1 */
+  const float* g2; const float* be2;       /* norm2 */
+} mmst_enc_params;
+
+typedef struct {  /* fp32 gradient buffers, same shapes as the parameters */
+  float* w_qkv; float* b_qkv; float* w_o; float* b_o; float* w_1; float* b_1; float* w_2; float* b_2;
+  float* g1; float* be1; float* g2; float* be2;
+} mmst_enc_grads;
+
+typedef struct {  /* activations of ONE layer for ONE sequence group */
+  const void* x;        /* in : [B*S][128] */
+  void* y;              /* out: [B*S][128] (or rows of a longer sequence, see y_L) */
+  const float* kbias;   /* [B][S] additive key bias, or NULL */
+  void* qkv;            /* [B*S][384] */
+  void* attn;           /* [B*S][128] attention output before out_proj */
+  float* lse;           /* [B][H][S] log2-sum-exp of the attention rows */
+  void* z1; float* st1; /* pre-norm1 sum [B*S][128], (mean, rstd) [B*S][2] */
+  void* x1;             /* norm1 output */
+  void* h;              /* relu(linear1) after dropout, [B*S][2048] */
+  void* z2; float* st2; /* pre-norm2 sum, (mean, rstd) */
+  int B, S;
+  int y_L, y_off;       /* if y_L > 0, output row (b, s) is written at row b*y_L + y_off + s of y */
+} mmst_enc_acts;
+
+typedef struct {  /* backward state of ONE layer for ONE sequence group */
+  const void* dz2;  /* in : grad at this layer's pre-norm2 sum [B*S][128] */
+  const void* dzd2; /* in : the same through the residual-dropout mask (== dz2 when drop_p == 0) */
+  void* dh; void* dz1; void* dzd1; void* da; void* dqkv; float* delta; /* scratch, sizes as forward */
+  void* dx;         /* out: grad w.r.t. x if prev_z2 == NULL, else grad at the PREVIOUS layer's pre-norm2 sum */
+  void* dxd;        /* out: previous layer's dzd2 (only when prev_z2 != NULL and drop_p > 0) */
+  const void* prev_z2; const float* prev_st2; const float* prev_g2; /* previous layer's norm2, or NULL */
+  float* prev_dg2; float* prev_dbe2;
+  uint32_t prev_seed; /* seed the previous layer was run with */
+} mmst_enc_bwd;
+
+/* x -> y for n sequence groups with independent parameters (the per-modality encoders run as one
+ * grouped launch sequence; encoder_cross is n = 1 with nhead = 4).  Replaces
+ * nn.TransformerEncoderLayer.forward as called from :846,:866,:886,:906,:927,:944. */
+int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
+                           uint32_t seed, void* stream);
+/* Backward of the above (what autograd does for the reference). */
+int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+
+/* ---- one post-norm decoder layer == nn.TransformerDecoderLayer(d_model=128, nhead=16) (:539-541) ---- */
+typedef struct {
+  const void* w_qkv; const float* b_qkv; const void* w_o; const float* b_o;      /* self_attn */
+  const void* w_cqkv; const float* b_cqkv; const void* w_co; const float* b_co;  /* multihead_attn */
+  const void* w_1; const float* b_1; const void* w_2; const float* b_2;
+  const float* g1; const float* be1; const float* g2; const float* be2; const float* g3; const float* be3;
+} mmst_dec_params;
+
+typedef struct {
+  float* w_qkv; float* b_qkv; float* w_o; float* b_o; float* w_cqkv; float* b_cqkv; float* w_co; float* b_co;
+  float* w_1; float* b_1; float* w_2; float* b_2; float* g1; float* be1; float* g2; float* be2; float* g3; float* be3;
+} mmst_dec_grads;
+
+typedef struct {
+  const void* x; void* y;             /* [B*T][128] */
+  const void* mem;                    /* encoder memory [B*L][128] */
+  const float* mem_bias;              /* [B][L] additive, or NULL */
+  void* qkv; void* attn1; float* lse1; void* z1; float* st1; void* x1;
+  void* qc; void* kvc; void* attn2; float* lse2; void* z2; float* st2; void* x2; /* qc [B*T][128], kvc [B*L][256] */
+  void* h; void* z3; float* st3;
+  int B, T, L;
+  int kv_ready; /* nonzero: kvc already holds this layer's K/V projection of mem (decode loops reuse it) */
+} mmst_dec_acts;
+
+typedef struct {
+  const void* dz3; const void* dzd3;
+  void* dh; void* dz2; void* dzd2; void* da; void* dqc; void* dkvc; void* dz1; void* dzd1; void* dqkv; float* delta;
+  void* dmem;       /* [B*L][128] grad w.r.t. memory */
+  int dmem_accumulate; /* 0: overwrite dmem, 1: add to it (layers after the first one processed) */
+  void* dx; void* dxd;
+  const void* prev_z3; const float* prev_st3; const float* prev_g3; float* prev_dg3; float* prev_dbe3;
+  uint32_t prev_seed;
+} mmst_dec_bwd;
+
+/* Replaces nn.TransformerDecoderLayer.forward as called from :963 (causal tgt_mask built in-kernel,
+ * memory_key_padding_mask = mem_bias) and, with T growing by one per step, from the decode loops
+ * (models_MMT_v15_4.py:1244, validate_generate_MMT_v15_4.py:751). */
+int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int nhead, float drop_p, uint32_t seed,
+                           void* stream);
+int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                           const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+
+/* Standalone LayerNorm backward (top of a layer stack): dy -> dz / dzd, accumulates dgamma, dbeta.
+ * dy row (b, s) is read at row b*dy_L + dy_off + s when dy_L > 0 (a slice of the concatenated memory). */
+int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,
+                       const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float drop_p,
+                       uint32_t seed, void* stream);
+
+/* ---- embeddings: replaces _embed_spectrum_* / _embed_MF / _embed_MS / _embed_MW and
+ * _create_embeddings_and_masks_* (:549-792): writes each modality's [B][S][128] input sequence and its
+ * additive key bias, plus the modality's slice of the global (cross-encoder) key bias. ---- */
+typedef struct {
+  void* xseq;            /* out [B][S][128] bf16 */
+  float* kbias;          /* out [B][S] */
+  float* kbias_glob;     /* out: row b at kbias_glob + b*L_glob + off_glob */
+  const float* src;      /* spectrum [B][64][in_dim] fp32 (NULL for IR: its single row comes from a GEMM) */
+  const float* mask;     /* [B][64] fp32, nonzero = padded */
+  const float* w; const float* b;   /* point embedding Linear(in_dim -> 128), fp32 */
+  float* dw; float* db;  /* gradients (backward only) */
+  void* ir_dpre;         /* IR only, backward: out [B][128] bf16 = grad before the ReLU of the IR row */
+  int in_dim;            /* 2 (1H, HSQC, COSY), 1 (13C), 0 (IR) */
+  int n_spec;            /* 64 spectrum rows, or 1 for IR */
+  int S, L_glob, off_glob;
+  int mod_bool;          /* 1: this modality's concatenated mask is all-bool (-inf semantics) */
+} mmst_embed_group;
+
+typedef struct {
+  const int64_t* mf_tok; const float* mf_mask; const float* mf_table; float* d_mf_table; int has_mf; int mf_bool;
+  const int64_t* ms_tok; const float* ms_mask; const float* ms_table; float* d_ms_table; int has_ms; int ms_bool;
+  const float* mw; const float* mw_w; const float* mw_b; float* d_mw_w; float* d_mw_b; int has_mw;
+  int B; int glob_bool; /* glob_bool: the concatenated global mask is all-bool */
+} mmst_embed_shared;
+
+int mmst_embed_fwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s, void* stream);
+/* dxseq[i]: grad w.r.t. group i's input sequence ([B][S][128] bf16) */
+int mmst_embed_bwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s, const void* const* dxseq,
+                   void* stream);
+
+/* mean over the sequence of memory [B][L][128] -> [B][128] bf16 (torch.mean(memory, dim=0), :946) */
+int mmst_seq_mean(const void* mem, void* out, int B, int L, void* stream);
+
+/* target embedding: out[b][t] = dropout(embed_trg[tok[t][b]] + pe_trg[t]) (:955-961); tok is (T,B) int64 with
+ * row stride tok_ld */
+int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const float* pos, void* out, int B, int T,
+                       float drop_p, uint32_t seed, void* stream);
+int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
+                       float drop_p, uint32_t seed, void* stream);
+
+/* CrossEntropyLoss() over all B*T positions (:70, :268-271): logits fp32 [B*T][ldl] (first V columns valid),
+ * target for row (b, t) = trg[b*trg_ld + t + 1].  Adds the mean loss to *loss and writes dlogits (bf16,
+ * [B*T][64], zero beyond V), scaled by grad_scale / (B*T). */
+int mmst_ce_loss(const float* logits, int ldl, int V, const int64_t* trg, int trg_ld, int B, int T, float* loss,
+                 void* dlogits, float grad_scale, void* stream);
+
+/* One decode step's token selection (softmax(logits/temperature), argmax, its probability) on the LAST
+ * position: validate_generate_MMT_v15_4.py:754-762 / models_MMT_v15_4.py:1246-1256.  logits [B][T][ldl]. */
+int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float temperature, int64_t* next_tok,
+                       float* next_prob, void* stream);
+
+/* torch.optim.AdamW step (:1213-1214) on flat fp32 buffers + refresh of the bf16 weight copy. */
+int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_bf16, long n, float lr, float beta1,
+               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* fp32 -> bf16 copy of a [rows][cols] matrix into a [rows][ld_out] one (padded weight copies). */
+int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, void* stream);
+
+int mmst_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -25,6 +25,7 @@ class GemmProb(C.Structure):
         ("Pn", C.c_int), ("Qn", C.c_int), ("K", C.c_int),
         ("flags", C.c_int),
         ("drop_p", C.c_float), ("seed", C.c_uint32),
+        ("cS", C.c_int), ("cL", C.c_int), ("coff", C.c_int), ("rS", C.c_int), ("rL", C.c_int), ("roff", C.c_int),
         ("ksplit", C.c_int), ("tile_begin", C.c_int),
         ("ptiles", C.c_int), ("qtiles", C.c_int),
     ]
@@ -84,3 +85,65 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+# layer-level structs of include/mmst.h
+# ---------------------------------------------------------------------------------------------
+def _ptrs(*names):
+    return [(n, C.c_void_p) for n in names]
+
+
+class EncParams(C.Structure):
+    _fields_ = _ptrs("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "g1", "be1", "g2", "be2")
+
+
+class EncGrads(C.Structure):
+    _fields_ = _ptrs("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "g1", "be1", "g2", "be2")
+
+
+class EncActs(C.Structure):
+    _fields_ = _ptrs("x", "y", "kbias", "qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2") + [
+        ("B", C.c_int), ("S", C.c_int), ("y_L", C.c_int), ("y_off", C.c_int)]
+
+
+class EncBwd(C.Structure):
+    _fields_ = _ptrs("dz2", "dzd2", "dh", "dz1", "dzd1", "da", "dqkv", "delta", "dx", "dxd",
+                     "prev_z2", "prev_st2", "prev_g2", "prev_dg2", "prev_dbe2") + [("prev_seed", C.c_uint32)]
+
+
+_DEC_P = ("w_qkv", "b_qkv", "w_o", "b_o", "w_cqkv", "b_cqkv", "w_co", "b_co", "w_1", "b_1", "w_2", "b_2",
+          "g1", "be1", "g2", "be2", "g3", "be3")
+
+
+class DecParams(C.Structure):
+    _fields_ = _ptrs(*_DEC_P)
+
+
+class DecGrads(C.Structure):
+    _fields_ = _ptrs(*_DEC_P)
+
+
+class DecActs(C.Structure):
+    _fields_ = _ptrs("x", "y", "mem", "mem_bias", "qkv", "attn1", "lse1", "z1", "st1", "x1", "qc", "kvc", "attn2",
+                     "lse2", "z2", "st2", "x2", "h", "z3", "st3") + [
+        ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int)]
+
+
+class DecBwd(C.Structure):
+    _fields_ = _ptrs("dz3", "dzd3", "dh", "dz2", "dzd2", "da", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta",
+                     "dmem") + [("dmem_accumulate", C.c_int)] + _ptrs(
+        "dx", "dxd", "prev_z3", "prev_st3", "prev_g3", "prev_dg3", "prev_dbe3") + [("prev_seed", C.c_uint32)]
+
+
+class EmbedGroup(C.Structure):
+    _fields_ = _ptrs("xseq", "kbias", "kbias_glob", "src", "mask", "w", "b", "dw", "db", "ir_dpre") + [
+        ("in_dim", C.c_int), ("n_spec", C.c_int), ("S", C.c_int), ("L_glob", C.c_int), ("off_glob", C.c_int),
+        ("mod_bool", C.c_int)]
+
+
+class EmbedShared(C.Structure):
+    _fields_ = (_ptrs("mf_tok", "mf_mask", "mf_table", "d_mf_table") + [("has_mf", C.c_int), ("mf_bool", C.c_int)] +
+                _ptrs("ms_tok", "ms_mask", "ms_table", "d_ms_table") + [("has_ms", C.c_int), ("ms_bool", C.c_int)] +
+                _ptrs("mw", "mw_w", "mw_b", "d_mw_w", "d_mw_b") + [("has_mw", C.c_int), ("B", C.c_int),
+                                                                    ("glob_bool", C.c_int)])

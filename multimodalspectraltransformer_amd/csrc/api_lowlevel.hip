@@ -1,5 +1,6 @@
 // Low-level C-ABI: the grouped GEMM and attention launchers, exported for the parity tests
-// and for the Python host layer.  Structs are plain C (see gemm.h / attn.h).
+// and for the one-off projections of the host layer (IR embedding, fingerprint head, vocabulary
+// projection and their gradients).  Structs are plain C (see gemm.h / attn.h).
 #include "attn.h"
 #include "gemm.h"
 

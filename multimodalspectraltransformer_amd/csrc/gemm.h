@@ -30,6 +30,9 @@ struct GemmProb {
   int Pn, Qn, K;
   int flags;
   float drop_p; uint32_t seed;
+  // Optional row remap for C (cS>0) and R (rS>0): logical row m = b*S + s lives at physical
+  // row b*L + off + s, i.e. a [B][S] sequence embedded in a longer [B][L] one.
+  int cS, cL, coff, rS, rL, roff;
   int ksplit;      // number of K slices (EPI_ATOMIC only), >= 1
   int tile_begin;  // filled by the launcher
   int ptiles, qtiles;

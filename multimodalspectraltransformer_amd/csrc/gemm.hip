@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   }
 
   const int q = lane >> 4;
+  auto crow = [&](int m) -> size_t { return pr.cS > 0 ? (size_t)(m / pr.cS) * pr.cL + pr.coff + (m % pr.cS) : (size_t)m; };
+  auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
   const uint32_t thr = drop_threshold(pr.drop_p);
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
 
@@ -230,15 +232,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
           if (pr.drop_p > 0.f) drop8(v, pr.seed, (uint32_t)m * (uint32_t)pr.Qn + n, thr, dscale);
           if (pr.R) {
             float r[8];
-            load8(r, pr.R + (size_t)m * pr.ldr + n);
+            load8(r, pr.R + rrow(m) * pr.ldr + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
           }
-          if (pr.flags & GF_OUT_F32) store8f((float*)pr.C + (size_t)m * pr.ldc + n, v);
-          else store8((bf16*)pr.C + (size_t)m * pr.ldc + n, v);
+          if (pr.flags & GF_OUT_F32) store8f((float*)pr.C + crow(m) * pr.ldc + n, v);
+          else store8((bf16*)pr.C + crow(m) * pr.ldc + n, v);
         } else if constexpr (EPI == EPI_DRELU) {
           float r[8];
-          load8(r, pr.R + (size_t)m * pr.ldr + n);
+          load8(r, pr.R + rrow(m) * pr.ldr + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = r[e] > 0.f ? v[e] * dscale : 0.f;
           store8((bf16*)pr.C + (size_t)m * pr.ldc + n, v);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
         if (pr.drop_p > 0.f) drop8(z[tp], pr.seed, (uint32_t)m * 128u + n, thr, dscale);
         if (ok && pr.R) {
           float r[8];
-          load8(r, pr.R + (size_t)m * pr.ldr + n);
+          load8(r, pr.R + rrow(m) * pr.ldr + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) z[tp][e] += r[e];
         }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
           float y[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] = (z[tp][e] - mean) * rstd * gam[tp][e] + bet[tp][e];
-          store8((bf16*)pr.C + (size_t)m * pr.ldc + n, y);
+          store8((bf16*)pr.C + crow(m) * pr.ldc + n, y);
         }
         if (q == 0 && pr.stats) { pr.stats[2 * (size_t)m] = mean; pr.stats[2 * (size_t)m + 1] = rstd; }
       }
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
         if (ok) {
           if (pr.R) {
             float r[8];
-            load8(r, pr.R + (size_t)m * pr.ldr + n);
+            load8(r, pr.R + rrow(m) * pr.ldr + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dy[e] += r[e];
           }

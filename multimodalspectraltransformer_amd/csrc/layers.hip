@@ -1,0 +1,394 @@
+// Layer-level entry points: each transformer layer is a fixed sequence of grouped GEMM and
+// attention launches (see gemm.h / attn.h).  Nothing is allocated and no state is kept here.
+#include "../../include/mmst.h"
+#include "attn.h"
+#include "gemm.h"
+#include <string.h>
+
+namespace {
+
+constexpr int D = MMST_D, FF = MMST_FF;
+
+inline GemmProb zero_prob() {
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.ksplit = 1;
+  return p;
+}
+
+// split-K factor for a weight-gradient GEMM: aim at >= 512 workgroups
+inline int pick_ksplit(int Pn, int Qn, int K) {
+  int tiles = ((Pn + 127) / 128) * ((Qn + 127) / 128);
+  int nk = (K + 63) / 64;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > nk) s = nk;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// C = P[M,K] * W[N,K]^T + bias (+relu, dropout)
+inline GemmProb fwd_linear(const void* x, int M, int K, const void* w, int N, const float* bias, void* out) {
+  GemmProb p = zero_prob();
+  p.P = (const bf16*)x; p.ldp = K;
+  p.Q = (const bf16*)w; p.ldq = K;
+  p.C = out; p.ldc = N; p.bias = bias;
+  p.Pn = M; p.Qn = N; p.K = K;
+  return p;
+}
+// dW[N,Kw] += dY[M,N]^T X[M,Kw]; db[N] += colsum(dY)
+inline GemmProb wgrad(const void* dy, int M, int N, const void* x, int Kw, float* dw, float* db) {
+  GemmProb p = zero_prob();
+  p.P = (const bf16*)dy; p.ldp = N;
+  p.Q = (const bf16*)x; p.ldq = Kw;
+  p.C = dw; p.ldc = Kw; p.dbias = db;
+  p.Pn = N; p.Qn = Kw; p.K = M;
+  p.ksplit = pick_ksplit(N, Kw, M);
+  return p;
+}
+// dX[M,Kw] = dY[M,N] W[N,Kw]
+inline GemmProb dgrad(const void* dy, int M, int N, const void* w, int Kw, void* dx) {
+  GemmProb p = zero_prob();
+  p.P = (const bf16*)dy; p.ldp = N;
+  p.Q = (const bf16*)w; p.ldq = Kw;
+  p.C = dx; p.ldc = Kw;
+  p.Pn = M; p.Qn = Kw; p.K = N;
+  return p;
+}
+
+#define RUN(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
+                           uint32_t seed, void* stream_) {
+  if (n < 1 || n > MMST_MAX_GROUPS || !p || !a || (nhead != 16 && nhead != 4)) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  const int hd = D / nhead;
+  GemmBatch gb;
+  AttnBatch ab;
+  // 1. fused QKV projection
+  gb.n = n;
+  for (int i = 0; i < n; ++i) gb.p[i] = fwd_linear(a[i].x, a[i].B * a[i].S, D, p[i].w_qkv, 3 * D, p[i].b_qkv, a[i].qkv);
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  // 2. attention
+  memset(&ab, 0, sizeof(ab));
+  ab.n = n; ab.hd = hd; ab.causal = 0; ab.drop_p = drop_p;
+  for (int i = 0; i < n; ++i) {
+    AttnProb& q = ab.p[i];
+    const bf16* qkv = (const bf16*)a[i].qkv;
+    q.Q = qkv; q.K = qkv + D; q.V = qkv + 2 * D;
+    q.ldq = q.ldk = q.ldv = 3 * D;
+    q.kbias = a[i].kbias;
+    q.O = (bf16*)a[i].attn; q.ldo = D;
+    q.lse = a[i].lse;
+    q.B = a[i].B; q.H = nhead; q.Tq = a[i].S; q.Sk = a[i].S;
+    q.seed = seed + 8 * i + 0;
+  }
+  RUN(launch_attn_fwd(ab, st));
+  // 3. out_proj + dropout + residual + norm1
+  for (int i = 0; i < n; ++i) {
+    GemmProb g = fwd_linear(a[i].attn, a[i].B * a[i].S, D, p[i].w_o, D, p[i].b_o, a[i].x1);
+    g.R = (const bf16*)a[i].x; g.ldr = D;
+    g.gamma = p[i].g1; g.beta = p[i].be1; g.Z = (bf16*)a[i].z1; g.stats = a[i].st1;
+    g.drop_p = drop_p; g.seed = seed + 8 * i + 1;
+    gb.p[i] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  // 4. linear1 + relu + dropout
+  for (int i = 0; i < n; ++i) {
+    GemmProb g = fwd_linear(a[i].x1, a[i].B * a[i].S, D, p[i].w_1, FF, p[i].b_1, a[i].h);
+    g.flags = GF_RELU; g.drop_p = drop_p; g.seed = seed + 8 * i + 2;
+    gb.p[i] = g;
+  }
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  // 5. linear2 + dropout + residual + norm2
+  for (int i = 0; i < n; ++i) {
+    GemmProb g = fwd_linear(a[i].h, a[i].B * a[i].S, FF, p[i].w_2, D, p[i].b_2, a[i].y);
+    g.R = (const bf16*)a[i].x1; g.ldr = D;
+    g.gamma = p[i].g2; g.beta = p[i].be2; g.Z = (bf16*)a[i].z2; g.stats = a[i].st2;
+    g.drop_p = drop_p; g.seed = seed + 8 * i + 3;
+    if (a[i].y_L > 0) { g.cS = a[i].S; g.cL = a[i].y_L; g.coff = a[i].y_off; }
+    gb.p[i] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  return MMST_OK;
+}
+
+int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  if (n < 1 || n > MMST_MAX_GROUPS || !p || !g || !a || !w || (nhead != 16 && nhead != 4)) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  const int hd = D / nhead;
+  GemmBatch gb;
+  gb.n = n;
+  // dW2, db2
+  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dzd2, a[i].B * a[i].S, D, a[i].h, FF, g[i].w_2, g[i].b_2);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  // dh = (dzd2 W2) * relu'/dropout mask
+  for (int i = 0; i < n; ++i) {
+    GemmProb q = dgrad(w[i].dzd2, a[i].B * a[i].S, D, p[i].w_2, FF, w[i].dh);
+    q.R = (const bf16*)a[i].h; q.ldr = FF; q.drop_p = drop_p;
+    gb.p[i] = q;
+  }
+  RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
+  // dW1, db1
+  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dh, a[i].B * a[i].S, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  // dx1 = dh W1 + dz2 -> norm1 backward
+  for (int i = 0; i < n; ++i) {
+    GemmProb q = dgrad(w[i].dh, a[i].B * a[i].S, FF, p[i].w_1, D, w[i].dz1);
+    q.R = (const bf16*)w[i].dz2; q.ldr = D;
+    q.Z = (bf16*)a[i].z1; q.stats = a[i].st1; q.gamma = p[i].g1;
+    q.C2 = drop_p > 0.f ? (bf16*)w[i].dzd1 : nullptr;
+    q.dgamma = g[i].g1; q.dbeta = g[i].be1;
+    q.drop_p = drop_p; q.seed = seed + 8 * i + 1;
+    gb.p[i] = q;
+  }
+  RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
+  // dWo, dbo ; da = dzd1 Wo
+  for (int i = 0; i < n; ++i) {
+    const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
+    gb.p[i] = wgrad(dzd1, a[i].B * a[i].S, D, a[i].attn, D, g[i].w_o, g[i].b_o);
+  }
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  for (int i = 0; i < n; ++i) {
+    const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
+    gb.p[i] = dgrad(dzd1, a[i].B * a[i].S, D, p[i].w_o, D, w[i].da);
+  }
+  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+  // attention backward -> dqkv
+  AttnBatch ab;
+  memset(&ab, 0, sizeof(ab));
+  ab.n = n; ab.hd = hd; ab.causal = 0; ab.drop_p = drop_p;
+  for (int i = 0; i < n; ++i) {
+    AttnProb& q = ab.p[i];
+    const bf16* qkv = (const bf16*)a[i].qkv;
+    bf16* dqkv = (bf16*)w[i].dqkv;
+    q.Q = qkv; q.K = qkv + D; q.V = qkv + 2 * D; q.ldq = q.ldk = q.ldv = 3 * D;
+    q.kbias = a[i].kbias;
+    q.O = (bf16*)a[i].attn; q.ldo = D; q.lse = a[i].lse;
+    q.dO = (const bf16*)w[i].da; q.lddo = D; q.delta = w[i].delta;
+    q.dQ = dqkv; q.dK = dqkv + D; q.dV = dqkv + 2 * D; q.lddq = q.lddk = q.lddv = 3 * D;
+    q.B = a[i].B; q.H = nhead; q.Tq = a[i].S; q.Sk = a[i].S;
+    q.seed = seed + 8 * i + 0;
+  }
+  RUN(launch_attn_bwd(ab, st));
+  // dWqkv, dbqkv
+  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dqkv, a[i].B * a[i].S, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  // dx = dqkv Wqkv + dz1 ; fused with the previous layer's norm2 backward when there is one
+  bool prev = w[0].prev_z2 != nullptr;
+  for (int i = 0; i < n; ++i) {
+    if ((w[i].prev_z2 != nullptr) != prev) return MMST_ERR_ARG;
+    GemmProb q = dgrad(w[i].dqkv, a[i].B * a[i].S, 3 * D, p[i].w_qkv, D, w[i].dx);
+    q.R = (const bf16*)w[i].dz1; q.ldr = D;
+    if (prev) {
+      q.Z = (bf16*)w[i].prev_z2; q.stats = (float*)w[i].prev_st2; q.gamma = w[i].prev_g2;
+      q.C2 = drop_p > 0.f ? (bf16*)w[i].dxd : nullptr;
+      q.dgamma = w[i].prev_dg2; q.dbeta = w[i].prev_dbe2;
+      q.drop_p = drop_p; q.seed = w[i].prev_seed + 8 * i + 3;
+    }
+    gb.p[i] = q;
+  }
+  RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
+  return MMST_OK;
+}
+
+int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,
+                       const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float drop_p,
+                       uint32_t seed, void* stream_) {
+  if (rows < 1 || !dy || !z || !stats || !gamma || !dz) return MMST_ERR_ARG;
+  GemmBatch gb;
+  gb.n = 1;
+  GemmProb q = zero_prob();
+  q.Pn = rows; q.Qn = D; q.K = 0; q.ldp = 8; q.ldq = 8;
+  q.C = dz; q.ldc = D;
+  q.C2 = (drop_p > 0.f) ? (bf16*)dzd : nullptr;
+  q.R = (const bf16*)dy; q.ldr = D;
+  if (dy_L > 0) { q.rS = dy_S; q.rL = dy_L; q.roff = dy_off; }
+  q.Z = (bf16*)z; q.stats = (float*)stats; q.gamma = gamma;
+  q.dgamma = dgamma; q.dbeta = dbeta;
+  q.drop_p = drop_p; q.seed = seed;
+  gb.p[0] = q;
+  return launch_gemm(gb, EPI_LNBWD, false, false, (hipStream_t)stream_);
+}
+
+int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int nhead, float drop_p, uint32_t seed,
+                           void* stream_) {
+  if (!p || !a || nhead != 16) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  const int hd = D / nhead, M = a->B * a->T, ML = a->B * a->L;
+  GemmBatch gb;
+  AttnBatch ab;
+  gb.n = 1;
+  // self-attention block
+  gb.p[0] = fwd_linear(a->x, M, D, p->w_qkv, 3 * D, p->b_qkv, a->qkv);
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  memset(&ab, 0, sizeof(ab));
+  ab.n = 1; ab.hd = hd; ab.causal = 1; ab.drop_p = drop_p;
+  {
+    AttnProb& q = ab.p[0];
+    const bf16* qkv = (const bf16*)a->qkv;
+    q.Q = qkv; q.K = qkv + D; q.V = qkv + 2 * D; q.ldq = q.ldk = q.ldv = 3 * D;
+    q.O = (bf16*)a->attn1; q.ldo = D; q.lse = a->lse1;
+    q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->T; q.seed = seed + 0;
+  }
+  RUN(launch_attn_fwd(ab, st));
+  {
+    GemmProb g = fwd_linear(a->attn1, M, D, p->w_o, D, p->b_o, a->x1);
+    g.R = (const bf16*)a->x; g.ldr = D; g.gamma = p->g1; g.beta = p->be1; g.Z = (bf16*)a->z1; g.stats = a->st1;
+    g.drop_p = drop_p; g.seed = seed + 1;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  // cross-attention block: q from x1, k/v from memory
+  gb.n = a->kv_ready ? 1 : 2;
+  gb.p[0] = fwd_linear(a->x1, M, D, p->w_cqkv, D, p->b_cqkv, a->qc);
+  gb.p[1] = fwd_linear(a->mem, ML, D, (const bf16*)p->w_cqkv + D * D, 2 * D, p->b_cqkv + D, a->kvc);
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  gb.n = 1;
+  ab.causal = 0;
+  {
+    AttnProb& q = ab.p[0];
+    memset(&q, 0, sizeof(q));
+    const bf16* kv = (const bf16*)a->kvc;
+    q.Q = (const bf16*)a->qc; q.ldq = D;
+    q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
+    q.kbias = a->mem_bias;
+    q.O = (bf16*)a->attn2; q.ldo = D; q.lse = a->lse2;
+    q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->L; q.seed = seed + 2;
+  }
+  RUN(launch_attn_fwd(ab, st));
+  {
+    GemmProb g = fwd_linear(a->attn2, M, D, p->w_co, D, p->b_co, a->x2);
+    g.R = (const bf16*)a->x1; g.ldr = D; g.gamma = p->g2; g.beta = p->be2; g.Z = (bf16*)a->z2; g.stats = a->st2;
+    g.drop_p = drop_p; g.seed = seed + 3;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  // feed-forward block
+  {
+    GemmProb g = fwd_linear(a->x2, M, D, p->w_1, FF, p->b_1, a->h);
+    g.flags = GF_RELU; g.drop_p = drop_p; g.seed = seed + 4;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  {
+    GemmProb g = fwd_linear(a->h, M, FF, p->w_2, D, p->b_2, a->y);
+    g.R = (const bf16*)a->x2; g.ldr = D; g.gamma = p->g3; g.beta = p->be3; g.Z = (bf16*)a->z3; g.stats = a->st3;
+    g.drop_p = drop_p; g.seed = seed + 5;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  return MMST_OK;
+}
+
+int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                           const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  if (!p || !g || !a || !w || nhead != 16) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  const int hd = D / nhead, M = a->B * a->T, ML = a->B * a->L;
+  const bool dr = drop_p > 0.f;
+  GemmBatch gb;
+  gb.n = 1;
+  // feed-forward block
+  gb.p[0] = wgrad(w->dzd3, M, D, a->h, FF, g->w_2, g->b_2);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  {
+    GemmProb q = dgrad(w->dzd3, M, D, p->w_2, FF, w->dh);
+    q.R = (const bf16*)a->h; q.ldr = FF; q.drop_p = drop_p;
+    gb.p[0] = q;
+  }
+  RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
+  gb.p[0] = wgrad(w->dh, M, FF, a->x2, D, g->w_1, g->b_1);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  {
+    GemmProb q = dgrad(w->dh, M, FF, p->w_1, D, w->dz2);
+    q.R = (const bf16*)w->dz3; q.ldr = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
+    q.C2 = dr ? (bf16*)w->dzd2 : nullptr; q.dgamma = g->g2; q.dbeta = g->be2;
+    q.drop_p = drop_p; q.seed = seed + 3;
+    gb.p[0] = q;
+  }
+  RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
+  const void* dzd2 = dr ? w->dzd2 : w->dz2;
+  // cross-attention block
+  gb.p[0] = wgrad(dzd2, M, D, a->attn2, D, g->w_co, g->b_co);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  gb.p[0] = dgrad(dzd2, M, D, p->w_co, D, w->da);
+  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+  AttnBatch ab;
+  memset(&ab, 0, sizeof(ab));
+  ab.n = 1; ab.hd = hd; ab.causal = 0; ab.drop_p = drop_p;
+  {
+    AttnProb& q = ab.p[0];
+    const bf16* kv = (const bf16*)a->kvc;
+    bf16* dkv = (bf16*)w->dkvc;
+    q.Q = (const bf16*)a->qc; q.ldq = D; q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
+    q.kbias = a->mem_bias; q.O = (bf16*)a->attn2; q.ldo = D; q.lse = a->lse2;
+    q.dO = (const bf16*)w->da; q.lddo = D; q.delta = w->delta;
+    q.dQ = (bf16*)w->dqc; q.lddq = D; q.dK = dkv; q.dV = dkv + D; q.lddk = q.lddv = 2 * D;
+    q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->L; q.seed = seed + 2;
+  }
+  RUN(launch_attn_bwd(ab, st));
+  gb.n = 2;
+  gb.p[0] = wgrad(w->dqc, M, D, a->x1, D, g->w_cqkv, g->b_cqkv);
+  gb.p[1] = wgrad(w->dkvc, ML, 2 * D, a->mem, D, g->w_cqkv + D * D, g->b_cqkv + D);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  gb.n = 1;
+  {
+    GemmProb q = dgrad(w->dkvc, ML, 2 * D, (const bf16*)p->w_cqkv + D * D, D, w->dmem);
+    if (w->dmem_accumulate) { q.R = (const bf16*)w->dmem; q.ldr = D; }
+    gb.p[0] = q;
+  }
+  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+  {
+    GemmProb q = dgrad(w->dqc, M, D, p->w_cqkv, D, w->dz1);
+    q.R = (const bf16*)w->dz2; q.ldr = D; q.Z = (bf16*)a->z1; q.stats = a->st1; q.gamma = p->g1;
+    q.C2 = dr ? (bf16*)w->dzd1 : nullptr; q.dgamma = g->g1; q.dbeta = g->be1;
+    q.drop_p = drop_p; q.seed = seed + 1;
+    gb.p[0] = q;
+  }
+  RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
+  const void* dzd1 = dr ? w->dzd1 : w->dz1;
+  // self-attention block
+  gb.p[0] = wgrad(dzd1, M, D, a->attn1, D, g->w_o, g->b_o);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  gb.p[0] = dgrad(dzd1, M, D, p->w_o, D, w->da);
+  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+  ab.causal = 1;
+  {
+    AttnProb& q = ab.p[0];
+    memset(&q, 0, sizeof(q));
+    const bf16* qkv = (const bf16*)a->qkv;
+    bf16* dqkv = (bf16*)w->dqkv;
+    q.Q = qkv; q.K = qkv + D; q.V = qkv + 2 * D; q.ldq = q.ldk = q.ldv = 3 * D;
+    q.O = (bf16*)a->attn1; q.ldo = D; q.lse = a->lse1;
+    q.dO = (const bf16*)w->da; q.lddo = D; q.delta = w->delta;
+    q.dQ = dqkv; q.dK = dqkv + D; q.dV = dqkv + 2 * D; q.lddq = q.lddk = q.lddv = 3 * D;
+    q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->T; q.seed = seed + 0;
+  }
+  RUN(launch_attn_bwd(ab, st));
+  gb.p[0] = wgrad(w->dqkv, M, 3 * D, a->x, D, g->w_qkv, g->b_qkv);
+  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  {
+    GemmProb q = dgrad(w->dqkv, M, 3 * D, p->w_qkv, D, w->dx);
+    q.R = (const bf16*)w->dz1; q.ldr = D;
+    bool prev = w->prev_z3 != nullptr;
+    if (prev) {
+      q.Z = (bf16*)w->prev_z3; q.stats = (float*)w->prev_st3; q.gamma = w->prev_g3;
+      q.C2 = dr ? (bf16*)w->dxd : nullptr; q.dgamma = w->prev_dg3; q.dbeta = w->prev_dbe3;
+      q.drop_p = drop_p; q.seed = w->prev_seed + 5;
+    }
+    gb.p[0] = q;
+    RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
+  }
+  return MMST_OK;
+}
+
+}  // extern "C"

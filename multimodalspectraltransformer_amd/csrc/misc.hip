@@ -1,0 +1,403 @@
+// Bandwidth-bound kernels around the transformer layers: spectrum / formula / weight embeddings and
+// sequence assembly, sequence mean, target embedding, cross-entropy, greedy token selection, AdamW.
+#include "../../include/mmst.h"
+#include "common.h"
+
+namespace {
+
+constexpr int D = MMST_D;
+
+struct EmbedArgs {
+  int n;
+  int row_begin[MMST_MAX_GROUPS + 1];  // prefix of B*S rows per group
+  mmst_embed_group g[MMST_MAX_GROUPS];
+  mmst_embed_shared s;
+};
+
+// additive bias of one mask component inside a concatenated mask:
+// all-bool concatenation -> -inf where set; otherwise bool components promote to 0/1 floats and float
+// components are added as they are.
+__device__ __forceinline__ float mask_bias(float mv, bool comp_bool, bool target_bool) {
+  if (target_bool) return mv != 0.f ? -INFINITY : 0.f;
+  return comp_bool ? (mv != 0.f ? 1.f : 0.f) : mv;
+}
+
+// one thread = one (row, 8-column chunk); 16 threads per row
+__global__ void embed_fwd_kernel(const EmbedArgs A) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 4, c0 = (gid & 15) * 8;
+  if (row >= A.row_begin[A.n]) return;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < MMST_MAX_GROUPS; ++i)
+    if (i < A.n && row >= A.row_begin[i]) gi = i;
+  const mmst_embed_group& G = A.g[gi];
+  const mmst_embed_shared& S = A.s;
+  const int lr = row - A.row_begin[gi];
+  const int b = lr / G.S, s = lr % G.S;
+  float v[8];
+  float mv = 0.f;
+  bool comp_bool = true, write_x = true;
+  int seg = s;
+  if (seg < G.n_spec) {
+    if (G.in_dim == 0) {
+      write_x = false;  // IR row: produced by the IR GEMM
+    } else {
+      const float* x = G.src + ((size_t)b * 64 + seg) * G.in_dim;
+      const float x0 = x[0], x1 = G.in_dim == 2 ? x[1] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* wr = G.w + (size_t)(c0 + e) * G.in_dim;
+        float a = wr[0] * x0 + G.b[c0 + e];
+        if (G.in_dim == 2) a += wr[1] * x1;
+        v[e] = fmaxf(a, 0.f);
+      }
+      mv = G.mask[(size_t)b * 64 + seg];
+    }
+  } else {
+    seg -= G.n_spec;
+    bool done = false;
+    if (S.has_mf) {
+      if (seg < 64) {
+        const int64_t tok = S.mf_tok[(size_t)b * 64 + seg];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(S.mf_table[(size_t)tok * D + c0 + e], 0.f);
+        mv = S.mf_mask[(size_t)b * 64 + seg];
+        comp_bool = S.mf_bool != 0;
+        done = true;
+      } else seg -= 64;
+    }
+    if (!done && S.has_ms) {
+      if (seg < 64) {
+        const int64_t tok = S.ms_tok[(size_t)b * 64 + seg];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(S.ms_table[(size_t)tok * D + c0 + e], 0.f);
+        mv = S.ms_mask[(size_t)b * 64 + seg];
+        comp_bool = S.ms_bool != 0;
+        done = true;
+      } else seg -= 64;
+    }
+    if (!done) {  // molecular-weight token
+      const float mw = S.mw[b];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(S.mw_w[c0 + e] * mw + S.mw_b[c0 + e], 0.f);
+    }
+  }
+  if (write_x) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>((bf16*)G.xseq + (size_t)lr * D + c0) = o;
+  }
+  if (c0 == 0) {
+    G.kbias[(size_t)b * G.S + s] = mask_bias(mv, comp_bool, G.mod_bool != 0);
+    if (G.kbias_glob) G.kbias_glob[(size_t)b * G.L_glob + G.off_glob + s] = mask_bias(mv, comp_bool, S.glob_bool != 0);
+  }
+}
+
+struct EmbedBwdArgs {
+  EmbedArgs e;
+  const bf16* dx[MMST_MAX_GROUPS];
+};
+
+// one block = one (group, batch element); thread = column.  Point-embedding and MW gradients are
+// reduced over the sequence in registers (one atomic per column per block); embedding-table rows
+// are scatter-added.
+__global__ void embed_bwd_kernel(const EmbedBwdArgs A) {
+  const int gi = blockIdx.y, b = blockIdx.x, c = threadIdx.x;
+  const mmst_embed_group& G = A.e.g[gi];
+  const mmst_embed_shared& S = A.e.s;
+  const bf16* dx = A.dx[gi] + (size_t)b * G.S * D;
+  const bf16* x = (const bf16*)G.xseq + (size_t)b * G.S * D;
+  int s = 0;
+  if (G.in_dim > 0) {
+    float dw0 = 0.f, dw1 = 0.f, db = 0.f;
+    for (; s < 64; ++s) {
+      float gsc = (float)x[s * D + c] > 0.f ? (float)dx[s * D + c] : 0.f;
+      const float* xin = G.src + ((size_t)b * 64 + s) * G.in_dim;
+      dw0 += gsc * xin[0];
+      if (G.in_dim == 2) dw1 += gsc * xin[1];
+      db += gsc;
+    }
+    atomicAdd(G.dw + (size_t)c * G.in_dim, dw0);
+    if (G.in_dim == 2) atomicAdd(G.dw + (size_t)c * G.in_dim + 1, dw1);
+    atomicAdd(G.db + c, db);
+  } else {
+    // IR row: its weight gradient is a GEMM; emit the gradient in front of the ReLU for it
+    if (G.ir_dpre) ((bf16*)G.ir_dpre)[(size_t)b * D + c] = (float)x[c] > 0.f ? dx[c] : (bf16)0.f;
+    s = G.n_spec;
+  }
+  if (S.has_mf) {
+    for (int t = 0; t < 64; ++t, ++s) {
+      const int64_t tok = S.mf_tok[(size_t)b * 64 + t];
+      if (tok != 0 && (float)x[s * D + c] > 0.f) atomicAdd(S.d_mf_table + (size_t)tok * D + c, (float)dx[s * D + c]);
+    }
+  }
+  if (S.has_ms) {
+    for (int t = 0; t < 64; ++t, ++s) {
+      const int64_t tok = S.ms_tok[(size_t)b * 64 + t];
+      if (tok != 0 && (float)x[s * D + c] > 0.f) atomicAdd(S.d_ms_table + (size_t)tok * D + c, (float)dx[s * D + c]);
+    }
+  }
+  if (S.has_mw) {
+    float gsc = (float)x[s * D + c] > 0.f ? (float)dx[s * D + c] : 0.f;
+    atomicAdd(S.d_mw_w + c, gsc * S.mw[b]);
+    atomicAdd(S.d_mw_b + c, gsc);
+  }
+}
+
+// mean over L rows: block = (batch element), 128 threads = columns, each strides over rows
+__global__ void seq_mean_kernel(const bf16* mem, bf16* out, int L) {
+  const int b = blockIdx.x, c = threadIdx.x & 127, part = threadIdx.x >> 7, nparts = blockDim.x >> 7;
+  __shared__ float red[8][128];
+  float s = 0.f;
+  const bf16* p = mem + (size_t)b * L * D;
+  for (int r = part; r < L; r += nparts) s += (float)p[(size_t)r * D + c];
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0) {
+    for (int i = 1; i < nparts; ++i) s += red[i][c];
+    out[(size_t)b * D + c] = (bf16)(s / (float)L);
+  }
+}
+
+__global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, const float* embed, const float* pos, bf16* out,
+                                     int B, int T, float drop_p, uint32_t seed) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 4, c0 = (gid & 15) * 8;
+  if (row >= B * T) return;
+  const int b = row / T, t = row % T;
+  const int64_t tk = tok[(size_t)t * tok_ld + b];
+  const uint32_t thr = drop_threshold(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = embed[(size_t)tk * D + c0 + e] + pos[(size_t)t * D + c0 + e];
+    if (drop_p > 0.f) v = drop_keep(seed, (uint32_t)row * D + c0 + e, thr) ? v * sc : 0.f;
+    o[e] = (bf16)v;
+  }
+  *reinterpret_cast<bf16x8*>(out + (size_t)row * D + c0) = o;
+}
+
+__global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16* dout, float* d_embed, float* d_pos,
+                                     int B, int T, float drop_p, uint32_t seed) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 4, c0 = (gid & 15) * 8;
+  if (row >= B * T) return;
+  const int b = row / T, t = row % T;
+  const int64_t tk = tok[(size_t)t * tok_ld + b];
+  const uint32_t thr = drop_threshold(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float g = (float)dout[(size_t)row * D + c0 + e];
+    if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c0 + e, thr) ? g * sc : 0.f;
+    atomicAdd(d_embed + (size_t)tk * D + c0 + e, g);
+    atomicAdd(d_pos + (size_t)t * D + c0 + e, g);
+  }
+}
+
+// one wave per row of logits (V <= 64)
+__global__ void ce_loss_kernel(const float* logits, int ldl, int V, const int64_t* trg, int trg_ld, int B, int T,
+                               float* loss, bf16* dlogits, float grad_scale) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * T) return;
+  const int b = row / T, t = row % T;
+  const float x = lane < V ? logits[(size_t)row * ldl + lane] : -INFINITY;
+  const float mx = wave_max(x);
+  const float e = lane < V ? __expf(x - mx) : 0.f;
+  const float se = wave_sum(e);
+  const int target = (int)trg[(size_t)b * trg_ld + t + 1];
+  const float inv_n = 1.0f / (float)(B * T);
+  if (lane == target) atomicAdd(loss, (mx + __logf(se) - x) * inv_n);
+  if (dlogits) {
+    float g = lane < V ? (e / se - (lane == target ? 1.f : 0.f)) * inv_n * grad_scale : 0.f;
+    dlogits[(size_t)row * 64 + lane] = (bf16)g;
+  }
+}
+
+// softmax(logits / temperature) of the last position, first-index argmax, its probability
+__global__ void greedy_select_kernel(const float* logits, int ldl, int V, int B, int T, float temperature,
+                                     int64_t* next_tok, float* next_prob) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float x = lane < V ? logits[((size_t)b * T + (T - 1)) * ldl + lane] / temperature : -INFINITY;
+  const float mx = wave_max(x);
+  const float e = lane < V ? __expf(x - mx) : 0.f;
+  const float se = wave_sum(e);
+  // first index attaining the maximum (torch.argmax tie rule)
+  unsigned long long m = __ballot(x == mx);
+  const int arg = __ffsll((long long)m) - 1;
+  if (lane == arg) {
+    next_tok[b] = arg;
+    next_prob[b] = e / se;
+  }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16* __restrict__ pb, long n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+      bf16x4 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gr = gg[e] * gscale;
+        float pe = pp[e] * (1.f - lr * wd);
+        mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+        vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+        float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pe -= (lr / bc1) * (mm[e] / denom);
+        pp[e] = pe;
+        ob[e] = (bf16)pe;
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp;
+      *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+      if (pb) *reinterpret_cast<bf16x4*>(pb + i) = ob;
+    } else {
+      for (long j = i; j < n; ++j) {
+        float gr = g[j] * gscale;
+        float pe = p[j] * (1.f - lr * wd);
+        float mj = b1 * m[j] + (1.f - b1) * gr;
+        float vj = b2 * v[j] + (1.f - b2) * gr * gr;
+        pe -= (lr / bc1) * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+        p[j] = pe; m[j] = mj; v[j] = vj;
+        if (pb) pb[j] = (bf16)pe;
+      }
+    }
+  }
+}
+
+__global__ void cast_kernel(const float* src, bf16* dst, int rows, int cols, int ld_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  dst[(size_t)r * ld_out + c] = (bf16)src[i];
+}
+
+int fill_embed_args(EmbedArgs& A, int n, const mmst_embed_group* g, const mmst_embed_shared* s) {
+  if (n < 1 || n > MMST_MAX_GROUPS || !g || !s || s->B < 1) return MMST_ERR_ARG;
+  A.n = n;
+  A.s = *s;
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    int want = g[i].n_spec + (s->has_mf ? 64 : 0) + (s->has_ms ? 64 : 0) + (s->has_mw ? 1 : 0);
+    if (g[i].S != want || (g[i].in_dim != 0 && g[i].n_spec != 64) || g[i].in_dim < 0 || g[i].in_dim > 2)
+      return MMST_ERR_ARG;
+    A.g[i] = g[i];
+    A.row_begin[i] = rows;
+    rows += s->B * g[i].S;
+  }
+  A.row_begin[n] = rows;
+  for (int i = n + 1; i <= MMST_MAX_GROUPS; ++i) A.row_begin[i] = rows;
+  return MMST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmst_embed_fwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s, void* stream) {
+  EmbedArgs A;
+  int rc = fill_embed_args(A, n, g, s);
+  if (rc) return rc;
+  const int threads = A.row_begin[n] * 16;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_embed_bwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s, const void* const* dxseq,
+                   void* stream) {
+  EmbedBwdArgs A;
+  int rc = fill_embed_args(A.e, n, g, s);
+  if (rc) return rc;
+  if (!dxseq) return MMST_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (!dxseq[i]) return MMST_ERR_ARG;
+    A.dx[i] = (const bf16*)dxseq[i];
+  }
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(s->B, n), dim3(D), 0, (hipStream_t)stream, A);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_seq_mean(const void* mem, void* out, int B, int L, void* stream) {
+  if (!mem || !out || B < 1 || L < 1) return MMST_ERR_ARG;
+  hipLaunchKernelGGL(seq_mean_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const bf16*)mem, (bf16*)out, L);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const float* pos, void* out, int B, int T,
+                       float drop_p, uint32_t seed, void* stream) {
+  if (!tok || !embed || !pos || !out || B < 1 || T < 1) return MMST_ERR_ARG;
+  const int threads = B * T * 16;
+  hipLaunchKernelGGL(trg_embed_fwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
+                     embed, pos, (bf16*)out, B, T, drop_p, seed);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
+                       float drop_p, uint32_t seed, void* stream) {
+  if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1) return MMST_ERR_ARG;
+  const int threads = B * T * 16;
+  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
+                     (const bf16*)dout, d_embed, d_pos, B, T, drop_p, seed);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_ce_loss(const float* logits, int ldl, int V, const int64_t* trg, int trg_ld, int B, int T, float* loss,
+                 void* dlogits, float grad_scale, void* stream) {
+  if (!logits || !trg || !loss || V < 1 || V > 64 || B < 1 || T < 1 || trg_ld < T + 1) return MMST_ERR_ARG;
+  const int rows = B * T;
+  hipLaunchKernelGGL(ce_loss_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, trg,
+                     trg_ld, B, T, loss, (bf16*)dlogits, grad_scale);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float temperature, int64_t* next_tok,
+                       float* next_prob, void* stream) {
+  if (!logits || !next_tok || !next_prob || V < 1 || V > 64 || B < 1 || T < 1 || !(temperature > 0.f))
+    return MMST_ERR_ARG;
+  hipLaunchKernelGGL(greedy_select_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, B, T,
+                     temperature, next_tok, next_prob);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_bf16, long n, float lr, float beta1,
+               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  if (!param || !grad || !m || !v || n < 1 || step < 1) return MMST_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     (bf16*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, void* stream) {
+  if (!src || !dst || rows < 1 || cols < 1 || ld_out < cols) return MMST_ERR_ARG;
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst,
+                     rows, cols, ld_out);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,656 @@
+"""Host-side execution engine: parameter arena, activation plans and the launch sequences that
+drive libmmst.so for the MultimodalTransformer forward / backward path.
+
+torch is used for device memory, streams and (in train.py) torch.distributed only; every
+arithmetic step of the hot path is a HIP kernel behind the C ABI of include/mmst.h.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+D = 128
+FF = 2048
+SPEC = ("1H", "13C", "HSQC", "COSY")
+ALL_MODS = ("1H", "13C", "HSQC", "COSY", "IR")
+LAYER_DROPOUT = 0.1  # torch default of nn.Transformer{En,De}coderLayer; the reference never overrides it
+VPAD = 64            # padded vocabulary width of the logits / fc_out rows
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class Arena:
+    """All parameters in ONE flat fp32 buffer (plus flat gradient, AdamW moments and bf16 copy).
+
+    Order = execution order (embeddings, modality-encoder layers interleaved by depth, cross
+    encoder, decoder, heads) so that backward completes gradient memory from the tail towards the
+    head and the data-parallel all-reduce can run on contiguous tail segments while earlier layers
+    are still in backward."""
+
+    def __init__(self, model, device):
+        self.device = device
+        named = dict(model.named_parameters())
+        nl, ndl = model.num_encoder_layers, model.num_decoder_layers
+        order = [k for k in named if not (k.startswith("encoder_") or k.startswith("decoder.") or
+                                          k.startswith("fp1.") or k.startswith("fc_out.") or
+                                          k.startswith("real_data_linear."))]
+        self.seg_embed_end_keys = len(order)
+        for l in range(nl):
+            for m in ALL_MODS:
+                order += [k for k in named if k.startswith(f"encoder_{m}.layers.{l}.")]
+        mark_modal = len(order)
+        for l in range(nl):
+            order += [k for k in named if k.startswith(f"encoder_cross.layers.{l}.")]
+        mark_cross = len(order)
+        for l in range(ndl):
+            order += [k for k in named if k.startswith(f"decoder.layers.{l}.")]
+        order += [k for k in named if k.startswith("fp1.") or k.startswith("fc_out.") or
+                  k.startswith("real_data_linear.")]
+        assert len(order) == len(named) and len(set(order)) == len(named)
+        self.offset, self.numel = {}, {}
+        off = 0
+        marks = {}
+        for i, k in enumerate(order):
+            if i == mark_modal:
+                marks["cross"] = off
+            if i == mark_cross:
+                marks["decoder"] = off
+            if i == self.seg_embed_end_keys:
+                marks["modal"] = off
+            p = named[k]
+            n = p.numel()
+            slots = n
+            if k in ("fc_out.weight", "real_data_linear.weight"):
+                slots = VPAD * D          # rows V..63 stay zero: the GEMMs run on a 64-row matrix
+            elif k in ("fc_out.bias", "real_data_linear.bias"):
+                slots = VPAD
+            self.offset[k] = off
+            self.numel[k] = n
+            off += _align(slots)
+        self.total = off
+        self.marks = marks
+        self.order = order
+        self.P = torch.zeros(off, dtype=torch.float32, device=device)
+        self.G = torch.zeros(off, dtype=torch.float32, device=device)
+        self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.M = None
+        self.V = None
+        for k in order:
+            p = named[k]
+            view = self.P[self.offset[k]: self.offset[k] + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self.named = named
+        self.shadow_stale = True
+
+    def owns(self, model):
+        for k in (self.order[0], self.order[-1]):
+            p = self.named[k]
+            if p.data_ptr() != self.P.data_ptr() + 4 * self.offset[k] or p.device != self.P.device:
+                return False
+        return True
+
+    def p32(self, k):
+        return self.P.data_ptr() + 4 * self.offset[k]
+
+    def g32(self, k):
+        return self.G.data_ptr() + 4 * self.offset[k]
+
+    def pb(self, k):
+        return self.Pb.data_ptr() + 2 * self.offset[k]
+
+    def grad_view(self, k):
+        p = self.named[k]
+        return self.G[self.offset[k]: self.offset[k] + p.numel()].view(p.shape)
+
+    def refresh_shadow(self):
+        L.check(L.lib().mmst_cast_bf16(C.c_void_p(self.P.data_ptr()), C.c_void_p(self.Pb.data_ptr()), 1,
+                                       self.total, self.total, L.stream_ptr()), "mmst_cast_bf16")
+        self.shadow_stale = False
+
+    def active_keys(self, mode):
+        """Parameters that receive a gradient in this training_mode (the reference leaves the others at
+        grad None, so AdamW never touches them, weight decay included): encoders / embeddings of absent
+        modalities, fp1 (the fingerprint is not part of the loss) and real_data_linear are excluded."""
+        tags = set(_mode_tags(mode))
+        for t in ("MF", "MS", "MW"):
+            if t in mode:
+                tags.add(t)
+        out = []
+        for k in self.order:
+            if k.startswith("fp1.") or k.startswith("real_data_linear."):
+                continue
+            skip = False
+            for t in ALL_MODS:
+                if (k.startswith(f"encoder_{t}.") or k.startswith(f"linear_spec_embedding_{t}.")) and t not in tags:
+                    skip = True
+            for t in ("MF", "MS", "MW"):
+                if k.startswith(f"linear_embedding_{t}.") and t not in tags:
+                    skip = True
+            if not skip:
+                out.append(k)
+        return out
+
+    def active_ranges(self, mode):
+        """Contiguous [lo, hi) element ranges of the flat buffers covering the active parameters."""
+        act = set(self.active_keys(mode))
+        ranges = []
+        for i, k in enumerate(self.order):
+            if k not in act:
+                continue
+            lo = self.offset[k]
+            hi = self.offset[self.order[i + 1]] if i + 1 < len(self.order) else self.total
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1][1] = hi
+            else:
+                ranges.append([lo, hi])
+        return [tuple(r) for r in ranges]
+
+    def attach_grads(self, mode=None):
+        act = set(self.active_keys(mode)) if mode is not None else None
+        for k, p in self.named.items():
+            p.grad = self.grad_view(k) if (act is None or k in act) else None
+
+
+class _Carver:
+    def __init__(self):
+        self.items = []
+        self.size = {torch.bfloat16: 0, torch.float32: 0, torch.int64: 0}
+
+    def take(self, n, dtype=torch.bfloat16):
+        off = self.size[dtype]
+        self.size[dtype] += _align(n, 128)
+        h = [dtype, off, n, None]
+        self.items.append(h)
+        return h
+
+    def finish(self, device):
+        self.buf = {dt: torch.zeros(max(n, 1), dtype=dt, device=device) for dt, n in self.size.items()}
+        for h in self.items:
+            h[3] = self.buf[h[0]].data_ptr() + h[1] * self.buf[h[0]].element_size()
+
+    def view(self, h, *shape):
+        return self.buf[h[0]][h[1]: h[1] + h[2]].view(*shape)
+
+
+def _P(h):
+    return h[3]
+
+
+class Plan:
+    """Buffers and prebuilt C structs for one (batch size, target length, training_mode)."""
+
+    def __init__(self, eng, B, T, mode):
+        self.eng, self.B, self.T, self.mode = eng, B, T, mode
+        m = eng.model
+        ar = eng.arena
+        nl, ndl = m.num_encoder_layers, m.num_decoder_layers
+        self.has_mf, self.has_ms, self.has_mw = "MF" in mode, "MS" in mode, "MW" in mode
+        tail = (64 if self.has_mf else 0) + (64 if self.has_ms else 0) + (1 if self.has_mw else 0)
+        feature_dim = 193 if self.has_ms else 129          # models_MMT_v15_4.py:834-835
+        feature_dim_IR = 130 if self.has_ms else 66
+        self.mods = []          # (name, S, offset in memory)
+        self.blank = []         # (name, rows, offset)
+        off = 0
+        for name in ALL_MODS:
+            if name in _mode_tags(mode):
+                S = (1 if name == "IR" else 64) + tail
+                self.mods.append((name, S, off))
+                off += S
+            else:
+                rows = 65 if name == "COSY" else (feature_dim_IR if name == "IR" else feature_dim)
+                self.blank.append((name, rows, off))
+                off += rows
+        self.Lmem = off
+        Lm = self.Lmem
+        cv = _Carver()
+        f32, bf = torch.float32, torch.bfloat16
+        # inputs / embeddings
+        self.ir_bf16 = cv.take(B * 1000)
+        self.xseq = {n: cv.take(B * S * D) for n, S, _ in self.mods}
+        self.kbias = {n: cv.take(B * S, f32) for n, S, _ in self.mods}
+        self.kbias_glob = cv.take(B * Lm, f32)
+        self.mem_in = cv.take(B * Lm * D)
+        self.memory = None
+
+        def enc_acts(M, Hh, S_):
+            return dict(qkv=cv.take(M * 3 * D), attn=cv.take(M * D), lse=cv.take(B * Hh * S_, f32), z1=cv.take(M * D),
+                        st1=cv.take(M * 2, f32), x1=cv.take(M * D), h=cv.take(M * FF), z2=cv.take(M * D),
+                        st2=cv.take(M * 2, f32), y=cv.take(M * D))
+
+        self.modal_acts = [[enc_acts(B * S, 16, S) for _, S, _ in self.mods] for _ in range(nl)]
+        self.cross_acts = [enc_acts(B * Lm, 4, Lm) for _ in range(nl)]
+        self.mean = cv.take(B * D)
+        self.fingerprint = cv.take(B * m.fingerprint_size, f32)
+        Tm = max(T, 1)
+        M = B * Tm
+        self.tok = cv.take((m.max_len + 1) * B, torch.int64)
+        self.trg_emb = cv.take(M * D)
+        self.dec_acts = []
+        for _ in range(ndl):
+            self.dec_acts.append(dict(
+                qkv=cv.take(M * 3 * D), attn1=cv.take(M * D), lse1=cv.take(B * 16 * Tm, f32), z1=cv.take(M * D),
+                st1=cv.take(M * 2, f32), x1=cv.take(M * D), qc=cv.take(M * D), kvc=cv.take(B * Lm * 2 * D),
+                attn2=cv.take(M * D), lse2=cv.take(B * 16 * Tm, f32), z2=cv.take(M * D), st2=cv.take(M * 2, f32),
+                x2=cv.take(M * D), h=cv.take(M * FF), z3=cv.take(M * D), st3=cv.take(M * 2, f32), y=cv.take(M * D)))
+        self.logits = cv.take(M * VPAD, f32)
+        self.dlogits = cv.take(M * VPAD)
+        self.loss = cv.take(1, f32)
+        self.next_prob = cv.take((m.max_len + 1) * B, f32)
+
+        # backward scratch
+        def bwd_scratch(Mr, Hh, S_):
+            return dict(dh=cv.take(Mr * FF), dz1=cv.take(Mr * D), dzd1=cv.take(Mr * D), da=cv.take(Mr * D),
+                        dqkv=cv.take(Mr * 3 * D), delta=cv.take(B * Hh * S_, f32),
+                        dzA=cv.take(Mr * D), dzdA=cv.take(Mr * D), dzB=cv.take(Mr * D), dzdB=cv.take(Mr * D))
+
+        self.modal_bwd = [bwd_scratch(B * S, 16, S) for _, S, _ in self.mods]
+        self.cross_bwd = bwd_scratch(B * Lm, 4, Lm)
+        self.dec_bwd = bwd_scratch(M, 16, max(Tm, 1))
+        self.dec_bwd.update(dz2=cv.take(M * D), dzd2=cv.take(M * D), dqc=cv.take(M * D), dkvc=cv.take(B * Lm * 2 * D))
+        self.dmem = cv.take(B * Lm * D)
+        self.dmem_in = cv.take(B * Lm * D)
+        self.dtrg = cv.take(M * D)
+        self.ir_dpre = cv.take(B * D)
+        cv.finish(eng.device)
+        self.cv = cv
+        # constant parts of the global key bias: blank blocks (float ones -> +1; blank IR is bool False -> 0)
+        kg = cv.view(self.kbias_glob, B, Lm)
+        for name, rows, o in self.blank:
+            kg[:, o:o + rows] = 0.0 if name == "IR" else 1.0
+        self._build_structs()
+
+    # ------------------------------------------------------------------
+    def _enc_params(self, prefix):
+        ar = self.eng.arena
+        p = L.EncParams()
+        g = L.EncGrads()
+        names = dict(w_qkv="self_attn.in_proj_weight", b_qkv="self_attn.in_proj_bias", w_o="self_attn.out_proj.weight",
+                     b_o="self_attn.out_proj.bias", w_1="linear1.weight", b_1="linear1.bias", w_2="linear2.weight",
+                     b_2="linear2.bias", g1="norm1.weight", be1="norm1.bias", g2="norm2.weight", be2="norm2.bias")
+        for f, k in names.items():
+            key = prefix + k
+            setattr(p, f, ar.pb(key) if f.startswith("w_") else ar.p32(key))
+            setattr(g, f, ar.g32(key))
+        return p, g
+
+    def _dec_params(self, prefix):
+        ar = self.eng.arena
+        p = L.DecParams()
+        g = L.DecGrads()
+        names = dict(w_qkv="self_attn.in_proj_weight", b_qkv="self_attn.in_proj_bias", w_o="self_attn.out_proj.weight",
+                     b_o="self_attn.out_proj.bias", w_cqkv="multihead_attn.in_proj_weight",
+                     b_cqkv="multihead_attn.in_proj_bias", w_co="multihead_attn.out_proj.weight",
+                     b_co="multihead_attn.out_proj.bias", w_1="linear1.weight", b_1="linear1.bias",
+                     w_2="linear2.weight", b_2="linear2.bias", g1="norm1.weight", be1="norm1.bias",
+                     g2="norm2.weight", be2="norm2.bias", g3="norm3.weight", be3="norm3.bias")
+        for f, k in names.items():
+            key = prefix + k
+            setattr(p, f, ar.pb(key) if f.startswith("w_") else ar.p32(key))
+            setattr(g, f, ar.g32(key))
+        return p, g
+
+    def _build_structs(self):
+        m, ar, B, T, Lm = self.eng.model, self.eng.arena, self.B, max(self.T, 1), self.Lmem
+        nl, ndl = m.num_encoder_layers, m.num_decoder_layers
+        n = len(self.mods)
+        self.n_groups = n
+        # ---- modality encoder layers (grouped) ----
+        self.modal_p, self.modal_g, self.modal_a, self.modal_w = [], [], [], []
+        self.modal_dzd, self.cross_dzd, self.dec_dzd = [], [], []   # (dz, dzd) input pointers per layer
+        for l in range(nl):
+            self.modal_dzd.append([])
+            P_, G_, A_, W_ = (L.EncParams * n)(), (L.EncGrads * n)(), (L.EncActs * n)(), (L.EncBwd * n)()
+            for i, (name, S, off) in enumerate(self.mods):
+                P_[i], G_[i] = self._enc_params(f"encoder_{name}.layers.{l}.")
+                a, acts = A_[i], self.modal_acts[l][i]
+                a.x = _P(self.xseq[name]) if l == 0 else _P(self.modal_acts[l - 1][i]["y"])
+                last = l == nl - 1
+                a.y = _P(self.mem_in) if last else _P(acts["y"])
+                a.y_L, a.y_off = (Lm, off) if last else (0, 0)
+                a.kbias = _P(self.kbias[name])
+                for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
+                    setattr(a, f, _P(acts[f]))
+                a.B, a.S = B, S
+                w, sc = W_[i], self.modal_bwd[i]
+                # dz buffers alternate between layers: layer l reads slot (l % 2), writes slot ((l-1) % 2)
+                rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
+                w.dz2, w.dzd2 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+                self.modal_dzd[l].append((w.dz2, w.dzd2))
+                for f in ("dh", "dz1", "dzd1", "da", "dqkv", "delta"):
+                    setattr(w, f, _P(sc[f]))
+                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                if l > 0:
+                    pa = self.modal_acts[l - 1][i]
+                    pk = f"encoder_{name}.layers.{l - 1}."
+                    w.prev_z2, w.prev_st2 = _P(pa["z2"]), _P(pa["st2"])
+                    w.prev_g2 = ar.p32(pk + "norm2.weight")
+                    w.prev_dg2, w.prev_dbe2 = ar.g32(pk + "norm2.weight"), ar.g32(pk + "norm2.bias")
+            self.modal_p.append(P_); self.modal_g.append(G_); self.modal_a.append(A_); self.modal_w.append(W_)
+        # ---- cross encoder ----
+        self.cross_p, self.cross_g, self.cross_a, self.cross_w = [], [], [], []
+        for l in range(nl):
+            P_, G_, A_, W_ = (L.EncParams * 1)(), (L.EncGrads * 1)(), (L.EncActs * 1)(), (L.EncBwd * 1)()
+            P_[0], G_[0] = self._enc_params(f"encoder_cross.layers.{l}.")
+            a, acts = A_[0], self.cross_acts[l]
+            a.x = _P(self.mem_in) if l == 0 else _P(self.cross_acts[l - 1]["y"])
+            a.y = _P(acts["y"])
+            a.kbias = _P(self.kbias_glob)
+            for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
+                setattr(a, f, _P(acts[f]))
+            a.B, a.S = B, Lm
+            w, sc = W_[0], self.cross_bwd
+            rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
+            w.dz2, w.dzd2 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+            self.cross_dzd.append((w.dz2, w.dzd2))
+            for f in ("dh", "dz1", "dzd1", "da", "dqkv", "delta"):
+                setattr(w, f, _P(sc[f]))
+            if l > 0:
+                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                pa, pk = self.cross_acts[l - 1], f"encoder_cross.layers.{l - 1}."
+                w.prev_z2, w.prev_st2 = _P(pa["z2"]), _P(pa["st2"])
+                w.prev_g2 = ar.p32(pk + "norm2.weight")
+                w.prev_dg2, w.prev_dbe2 = ar.g32(pk + "norm2.weight"), ar.g32(pk + "norm2.bias")
+            else:
+                w.dx = _P(self.dmem_in)
+            self.cross_p.append(P_); self.cross_g.append(G_); self.cross_a.append(A_); self.cross_w.append(W_)
+        self.memory = self.cross_acts[nl - 1]["y"]
+        # ---- decoder ----
+        self.dec_p, self.dec_g, self.dec_a, self.dec_w = [], [], [], []
+        for l in range(ndl):
+            P_, G_ = self._dec_params(f"decoder.layers.{l}.")
+            a, acts = L.DecActs(), self.dec_acts[l]
+            a.x = _P(self.trg_emb) if l == 0 else _P(self.dec_acts[l - 1]["y"])
+            a.y = _P(acts["y"])
+            a.mem = _P(self.memory)
+            a.mem_bias = _P(self.kbias_glob)
+            for f in ("qkv", "attn1", "lse1", "z1", "st1", "x1", "qc", "kvc", "attn2", "lse2", "z2", "st2", "x2", "h",
+                      "z3", "st3"):
+                setattr(a, f, _P(acts[f]))
+            a.B, a.T, a.L = B, T, Lm
+            w, sc = L.DecBwd(), self.dec_bwd
+            rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
+            w.dz3, w.dzd3 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+            self.dec_dzd.append((w.dz3, w.dzd3))
+            for f in ("dh", "dz2", "dzd2", "da", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta"):
+                setattr(w, f, _P(sc[f]))
+            w.dmem = _P(self.dmem)
+            w.dmem_accumulate = 0 if l == ndl - 1 else 1
+            if l > 0:
+                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                pa, pk = self.dec_acts[l - 1], f"decoder.layers.{l - 1}."
+                w.prev_z3, w.prev_st3 = _P(pa["z3"]), _P(pa["st3"])
+                w.prev_g3 = ar.p32(pk + "norm3.weight")
+                w.prev_dg3, w.prev_dbe3 = ar.g32(pk + "norm3.weight"), ar.g32(pk + "norm3.bias")
+            else:
+                w.dx = _P(self.dtrg)
+            self.dec_p.append(P_); self.dec_g.append(G_); self.dec_a.append(a); self.dec_w.append(w)
+
+    def set_T(self, T, kv_ready=0):
+        """Decode loops re-run the decoder with a growing prefix in the same buffers."""
+        for a in self.dec_a:
+            a.T = T
+            a.kv_ready = kv_ready
+        self.T = T
+
+
+def _mode_tags(mode):
+    """Substring gating exactly as the reference does it (`"1H" in training_mode`, ...)."""
+    return [t for t in ALL_MODS if t in mode]
+
+
+_EMB_KEYS = {
+    "1H": "linear_spec_embedding_1H.point_embedding_layer_1H.fc_H",
+    "13C": "linear_spec_embedding_13C.point_embedding_layer_13C.fc_C",
+    "HSQC": "linear_spec_embedding_HSQC.point_embedding_layer_HSQC.fc_HSQC",
+    "COSY": "linear_spec_embedding_COSY.point_embedding_layer_COSY.fc_COSY",
+    "IR": "linear_spec_embedding_IR.linear_spec_embedding_IR",
+}
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.arena = None
+        self.plans = {}
+        self.device = None
+        self.step_seed = 0x1234567
+
+    # ------------------------------------------------------------------
+    def ensure(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise L.MMSTError("the MultimodalTransformer hot path runs on an MI355X only (device must be cuda); "
+                              "there is no CPU implementation in this package")
+        L.lib()
+        if self.arena is None or self.device != device or not self.arena.owns(self.model):
+            self.device = device
+            self.arena = Arena(self.model, device)
+            self.plans = {}
+        if self.arena.shadow_stale or self.model.training and self.model._external_optimizer:
+            self.arena.refresh_shadow()
+
+    def plan(self, B, T, mode):
+        key = (B, T, mode)
+        pl = self.plans.get(key)
+        if pl is None:
+            pl = Plan(self, B, T, mode)
+            self.plans[key] = pl
+        return pl
+
+    def layer_seed(self, uid):
+        return (self.step_seed * 2654435761 + uid * 64) & 0xFFFFFFFF
+
+    # ------------------------------------------------------------------
+    def _embed_structs(self, pl, batch, backward=False):
+        ar, n, B = self.arena, pl.n_groups, pl.B
+        G_ = (L.EmbedGroup * n)()
+        keep = []
+
+        def f32(t):
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        mode = pl.mode
+        mf_mask, ms_mask = batch.get("mask_MF"), batch.get("mask_MS")
+        mf_bool = bool(pl.has_mf and mf_mask is not None and mf_mask.dtype == torch.bool)
+        ms_bool = bool(pl.has_ms and ms_mask is not None and ms_mask.dtype == torch.bool)
+        comps_bool = (not pl.has_mf or mf_bool) and (not pl.has_ms or ms_bool)
+        # per-modality concatenated mask: bool only if every component is bool (spectrum, IR and MW masks are)
+        mod_bool = comps_bool
+        # global mask: additionally every blank 1H/13C/HSQC/COSY block is a float block of ones
+        glob_bool = comps_bool and all(name == "IR" for name, _, _ in pl.blank)
+        for i, (name, S, off) in enumerate(pl.mods):
+            g = G_[i]
+            g.xseq, g.kbias = _P(pl.xseq[name]), _P(pl.kbias[name])
+            g.kbias_glob = _P(pl.kbias_glob)
+            g.S, g.L_glob, g.off_glob, g.mod_bool = S, pl.Lmem, off, int(mod_bool)
+            key = _EMB_KEYS[name]
+            if name == "IR":
+                g.in_dim, g.n_spec = 0, 1
+                g.ir_dpre = _P(pl.ir_dpre)
+            else:
+                g.in_dim, g.n_spec = (1 if name == "13C" else 2), 64
+                g.src, g.mask = f32(batch["src_" + name]), f32(batch["mask_" + name])
+                g.w, g.b = ar.p32(key + ".weight"), ar.p32(key + ".bias")
+                g.dw, g.db = ar.g32(key + ".weight"), ar.g32(key + ".bias")
+        s = L.EmbedShared()
+        s.B, s.glob_bool = B, int(glob_bool)
+        s.has_mf, s.has_ms, s.has_mw = int(pl.has_mf), int(pl.has_ms), int(pl.has_mw)
+        if pl.has_mf:
+            t = batch["src_MF"].to(self.device, torch.int64).contiguous()
+            keep.append(t)
+            s.mf_tok, s.mf_mask, s.mf_bool = t.data_ptr(), f32(mf_mask), int(mf_bool)
+            s.mf_table = ar.p32("linear_embedding_MF.embedding.weight")
+            s.d_mf_table = ar.g32("linear_embedding_MF.embedding.weight")
+        if pl.has_ms:
+            t = batch["src_MS"].to(self.device, torch.int64).contiguous()
+            keep.append(t)
+            s.ms_tok, s.ms_mask, s.ms_bool = t.data_ptr(), f32(ms_mask), int(ms_bool)
+            s.ms_table = ar.p32("linear_embedding_MS.embedding.weight")
+            s.d_ms_table = ar.g32("linear_embedding_MS.embedding.weight")
+        if pl.has_mw:
+            s.mw = f32(batch["trg_MW"].reshape(-1))
+            k = "linear_embedding_MW.linear_spec_embedding_MW"
+            s.mw_w, s.mw_b = ar.p32(k + ".weight"), ar.p32(k + ".bias")
+            s.d_mw_w, s.d_mw_b = ar.g32(k + ".weight"), ar.g32(k + ".bias")
+        return G_, s, keep, glob_bool
+
+    # ------------------------------------------------------------------
+    def encode(self, pl, batch, train):
+        """Embeddings + modality encoders + cross encoder + fingerprint head."""
+        lib, st, ar, B, Lm = L.lib(), L.stream_ptr(), self.arena, pl.B, pl.Lmem
+        m = self.model
+        p_drop = LAYER_DROPOUT if train else 0.0
+        G_, s, keep, glob_bool = self._embed_structs(pl, batch)
+        pl.embed_structs = (G_, s, keep)
+        pl.mask_is_bool = glob_bool
+        L.check(lib.mmst_embed_fwd(pl.n_groups, G_, C.byref(s), st), "mmst_embed_fwd")
+        names = [n for n, _, _ in pl.mods]
+        if "IR" in names:
+            S_ir = dict((n, S) for n, S, _ in pl.mods)["IR"]
+            src = batch["src_IR"].to(self.device, torch.float32).contiguous()
+            keep.append(src)
+            L.check(lib.mmst_cast_bf16(C.c_void_p(src.data_ptr()), C.c_void_p(_P(pl.ir_bf16)), B, 1000, 1000, st),
+                    "mmst_cast_bf16")
+            k = _EMB_KEYS["IR"]
+            ops.gemm([dict(P=_P(pl.ir_bf16), Q=ar.pb(k + ".weight"), C=_P(pl.xseq["IR"]), bias=ar.p32(k + ".bias"),
+                           ldp=1000, ldq=1000, ldc=S_ir * D, Pn=B, Qn=D, K=1000, flags=L.GF_RELU)], L.EPI_BIAS)
+        nl = m.num_encoder_layers
+        for l in range(nl):
+            L.check(lib.mmst_encoder_layer_fwd(pl.n_groups, pl.modal_p[l], pl.modal_a[l], 16, C.c_float(p_drop),
+                                               C.c_uint32(self.layer_seed(l)), st), "mmst_encoder_layer_fwd")
+        for l in range(nl):
+            L.check(lib.mmst_encoder_layer_fwd(1, pl.cross_p[l], pl.cross_a[l], m.cross_heads, C.c_float(p_drop),
+                                               C.c_uint32(self.layer_seed(32 + l)), st), "mmst_encoder_layer_fwd")
+        L.check(lib.mmst_seq_mean(C.c_void_p(_P(pl.memory)), C.c_void_p(_P(pl.mean)), B, Lm, st), "mmst_seq_mean")
+        ops.gemm([dict(P=_P(pl.mean), Q=ar.pb("fp1.weight"), C=_P(pl.fingerprint), bias=ar.p32("fp1.bias"),
+                       ldp=D, ldq=D, ldc=m.fingerprint_size, Pn=B, Qn=m.fingerprint_size, K=D,
+                       flags=L.GF_OUT_F32)], L.EPI_BIAS)
+
+    def decode(self, pl, train, T=None, embed=True, kv_ready=0, tok_ptr=None):
+        """Target embedding + decoder + vocabulary projection on the tokens held in pl.tok[:T]."""
+        lib, st, ar, B = L.lib(), L.stream_ptr(), self.arena, pl.B
+        m = self.model
+        T = pl.T if T is None else T
+        if T != pl.dec_a[0].T or kv_ready != pl.dec_a[0].kv_ready:
+            pl.set_T(T, kv_ready)
+        p_drop = LAYER_DROPOUT if train else 0.0
+        p_drop2 = float(m.config.drop_out) if train else 0.0
+        if embed:
+            L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok_ptr or _P(pl.tok)), B, C.c_void_p(ar.p32("embed_trg.weight")),
+                                           C.c_void_p(ar.p32("pe_trg.weight")), C.c_void_p(_P(pl.trg_emb)), B, T,
+                                           C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)), st),
+                    "mmst_trg_embed_fwd")
+        for l in range(m.num_decoder_layers):
+            L.check(lib.mmst_decoder_layer_fwd(C.byref(pl.dec_p[l]), C.byref(pl.dec_a[l]), 16, C.c_float(p_drop),
+                                               C.c_uint32(self.layer_seed(64 + l)), st), "mmst_decoder_layer_fwd")
+        out = pl.dec_acts[m.num_decoder_layers - 1]["y"]
+        ops.gemm([dict(P=_P(out), Q=ar.pb("fc_out.weight"), C=_P(pl.logits), bias=ar.p32("fc_out.bias"),
+                       ldp=D, ldq=D, ldc=VPAD, Pn=B * T, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
+
+    def ce_loss(self, pl, trg_enc_SMI, grad_scale=1.0, want_grad=True):
+        """CrossEntropyLoss over all positions (PAD included); fills pl.dlogits."""
+        lib, st = L.lib(), L.stream_ptr()
+        trg = trg_enc_SMI.to(self.device, torch.int64).contiguous()
+        pl._trg_keep = trg
+        pl.cv.view(pl.loss, 1).zero_()
+        L.check(lib.mmst_ce_loss(C.c_void_p(_P(pl.logits)), VPAD, self.model.out_size, C.c_void_p(trg.data_ptr()),
+                                 trg.shape[1], pl.B, pl.T, C.c_void_p(_P(pl.loss)),
+                                 C.c_void_p(_P(pl.dlogits)) if want_grad else None, C.c_float(grad_scale), st),
+                "mmst_ce_loss")
+        return pl.cv.view(pl.loss, 1)
+
+    # ------------------------------------------------------------------
+    def backward(self, pl, train, on_segment=None):
+        """Backward of decode() + encode() from pl.dlogits; accumulates into the flat gradient buffer.
+        on_segment(name) is called when the gradient memory of 'decoder', 'cross', 'modal' is final."""
+        lib, st, ar, B, T, Lm = L.lib(), L.stream_ptr(), self.arena, pl.B, pl.T, pl.Lmem
+        m = self.model
+        nl, ndl = m.num_encoder_layers, m.num_decoder_layers
+        p_drop = LAYER_DROPOUT if train else 0.0
+        p_drop2 = float(m.config.drop_out) if train else 0.0
+        M = B * T
+        # vocabulary projection
+        last = pl.dec_acts[ndl - 1]
+        ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
+                       ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(64, M // 64)))],
+                 L.EPI_ATOMIC, pt=True, qt=True)
+        sc = pl.dec_bwd
+        rd = "A" if (ndl - 1) % 2 == 0 else "B"
+        ops.gemm([dict(P=_P(pl.dlogits), Q=ar.pb("fc_out.weight"), C=_P(sc["dz" + rd]),
+                       C2=_P(sc["dzd" + rd]) if p_drop > 0 else None, Z=_P(last["z3"]), stats=_P(last["st3"]),
+                       gamma=ar.p32(f"decoder.layers.{ndl - 1}.norm3.weight"),
+                       dgamma=ar.g32(f"decoder.layers.{ndl - 1}.norm3.weight"),
+                       dbeta=ar.g32(f"decoder.layers.{ndl - 1}.norm3.bias"),
+                       ldp=VPAD, ldq=D, ldc=D, Pn=M, Qn=D, K=VPAD, drop_p=p_drop,
+                       seed=(self.layer_seed(64 + ndl - 1) + 5) & 0xFFFFFFFF)], L.EPI_LNBWD, qt=True)
+        for l in reversed(range(ndl)):
+            w = pl.dec_w[l]
+            w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
+            w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
+            L.check(lib.mmst_decoder_layer_bwd(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
+                                               C.byref(w), 16, C.c_float(p_drop), C.c_uint32(self.layer_seed(64 + l)),
+                                               st), "mmst_decoder_layer_bwd")
+        L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
+                                       C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
+                                       B, T, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)), st),
+                "mmst_trg_embed_bwd")
+        if on_segment:
+            on_segment("decoder")
+        # cross encoder
+        sc = pl.cross_bwd
+        rd = "A" if (nl - 1) % 2 == 0 else "B"
+        lastc = pl.cross_acts[nl - 1]
+        pk = f"encoder_cross.layers.{nl - 1}."
+        L.check(lib.mmst_layernorm_bwd(B * Lm, C.c_void_p(_P(pl.dmem)), 0, 0, 0, C.c_void_p(_P(lastc["z2"])),
+                                       C.c_void_p(_P(lastc["st2"])), C.c_void_p(ar.p32(pk + "norm2.weight")),
+                                       C.c_void_p(_P(sc["dz" + rd])), C.c_void_p(_P(sc["dzd" + rd])),
+                                       C.c_void_p(ar.g32(pk + "norm2.weight")), C.c_void_p(ar.g32(pk + "norm2.bias")),
+                                       C.c_float(p_drop), C.c_uint32((self.layer_seed(32 + nl - 1) + 3) & 0xFFFFFFFF),
+                                       st), "mmst_layernorm_bwd")
+        for l in reversed(range(nl)):
+            pl.cross_w[l][0].prev_seed = self.layer_seed(32 + l - 1) if l > 0 else 0
+            pl.cross_w[l][0].dzd2 = pl.cross_dzd[l][1] if p_drop > 0 else pl.cross_dzd[l][0]
+            L.check(lib.mmst_encoder_layer_bwd(1, pl.cross_p[l], pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
+                                               m.cross_heads, C.c_float(p_drop), C.c_uint32(self.layer_seed(32 + l)),
+                                               st), "mmst_encoder_layer_bwd")
+        if on_segment:
+            on_segment("cross")
+        # modality encoders: top LayerNorm backward reads its slice of d(memory_in)
+        rd = "A" if (nl - 1) % 2 == 0 else "B"
+        groups = []
+        for i, (name, S, off) in enumerate(pl.mods):
+            acts, scm = pl.modal_acts[nl - 1][i], pl.modal_bwd[i]
+            pk = f"encoder_{name}.layers.{nl - 1}."
+            groups.append(dict(C=_P(scm["dz" + rd]), C2=_P(scm["dzd" + rd]) if p_drop > 0 else None,
+                               R=_P(pl.dmem_in), ldr=D, rS=S, rL=Lm, roff=off, Z=_P(acts["z2"]), stats=_P(acts["st2"]),
+                               gamma=ar.p32(pk + "norm2.weight"), dgamma=ar.g32(pk + "norm2.weight"),
+                               dbeta=ar.g32(pk + "norm2.bias"), ldp=8, ldq=8, ldc=D, Pn=B * S, Qn=D, K=0,
+                               drop_p=p_drop, seed=(self.layer_seed(nl - 1) + 8 * i + 3) & 0xFFFFFFFF))
+        ops.gemm(groups, L.EPI_LNBWD)
+        for l in reversed(range(nl)):
+            for i in range(pl.n_groups):
+                pl.modal_w[l][i].prev_seed = self.layer_seed(l - 1) if l > 0 else 0
+                pl.modal_w[l][i].dzd2 = pl.modal_dzd[l][i][1] if p_drop > 0 else pl.modal_dzd[l][i][0]
+            L.check(lib.mmst_encoder_layer_bwd(pl.n_groups, pl.modal_p[l], pl.modal_g[l], pl.modal_a[l], pl.modal_w[l],
+                                               16, C.c_float(p_drop), C.c_uint32(self.layer_seed(l)), st),
+                    "mmst_encoder_layer_bwd")
+        # embeddings
+        G_, s, keep = pl.embed_structs
+        wr = "B" if 0 % 2 == 0 else "A"
+        dx = (C.c_void_p * pl.n_groups)(*[_P(pl.modal_bwd[i]["dz" + wr]) for i in range(pl.n_groups)])
+        L.check(lib.mmst_embed_bwd(pl.n_groups, G_, C.byref(s), dx, st), "mmst_embed_bwd")
+        names = [n for n, _, _ in pl.mods]
+        if "IR" in names:
+            k = _EMB_KEYS["IR"]
+            ops.gemm([dict(P=_P(pl.ir_dpre), Q=_P(pl.ir_bf16), C=ar.g32(k + ".weight"), dbias=ar.g32(k + ".bias"),
+                           ldp=D, ldq=1000, ldc=1000, Pn=D, Qn=1000, K=B, ksplit=1)], L.EPI_ATOMIC, pt=True, qt=True)
+        if on_segment:
+            on_segment("modal")

@@ -1,0 +1,510 @@
+"""Drop-in module surface of the reference's utils_MMT/models_MMT_v15_4.py, executed by libmmst.so.
+
+`MultimodalTransformer(config)` keeps the reference's constructor, forward signature, return
+values, attribute names and state_dict keys (models_MMT_v15_4.py:487-976); the arithmetic runs
+in hand-written HIP kernels (include/mmst.h).  There is no CPU path: calling forward on a CPU
+device, or without the built library, raises.
+
+Layout note: the reference is sequence-first (S, B, d).  Internally everything is batch-first
+bf16; tensors handed back to callers are sequence-first fp32 views/copies with the reference's
+shapes, so callers written for the reference keep working.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .engine import D, FF, LAYER_DROPOUT, VPAD, Engine, _P
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (names chosen so that state_dict keys equal the reference's)
+# ---------------------------------------------------------------------------------------------
+class _Linear(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(fin)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        """Kernel-backed y = x W^T + b for callers that reach into the model (fc_out, fp1)."""
+        return _engine_of(self).linear(self, x)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, n, d, padding_idx=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n, d))
+        self.padding_idx = padding_idx
+        if padding_idx is not None:
+            with torch.no_grad():
+                self.weight[padding_idx].zero_()
+
+    def forward(self, idx):
+        return self.weight[idx]  # table lookup for callers that reach into the model (embed_trg, pe_trg)
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        self.eps = 1e-5
+
+
+class _MHA(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.linear1 = _Linear(d, FF)
+        self.linear2 = _Linear(FF, d)
+        self.norm1 = _LayerNorm(d)
+        self.norm2 = _LayerNorm(d)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.multihead_attn = _MHA(d)
+        self.linear1 = _Linear(d, FF)
+        self.linear2 = _Linear(FF, d)
+        self.norm1 = _LayerNorm(d)
+        self.norm2 = _LayerNorm(d)
+        self.norm3 = _LayerNorm(d)
+
+
+class SpectralEncoder(nn.Module):
+    """Stands in for nn.TransformerEncoder(nn.TransformerEncoderLayer(128, nhead), num_layers)."""
+
+    def __init__(self, name, d, nhead, num_layers):
+        super().__init__()
+        self.name_, self.nhead = name, nhead
+        self.layers = nn.ModuleList([_EncoderLayer(d) for _ in range(num_layers)])
+
+    def forward(self, src, mask=None, src_key_padding_mask=None):
+        return _engine_of(self).run_encoder(self, src, src_key_padding_mask)
+
+
+class SmilesDecoder(nn.Module):
+    """Stands in for nn.TransformerDecoder(nn.TransformerDecoderLayer(128, 16), num_layers)."""
+
+    def __init__(self, d, nhead, num_layers):
+        super().__init__()
+        self.nhead = nhead
+        self.layers = nn.ModuleList([_DecoderLayer(d) for _ in range(num_layers)])
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        return _engine_of(self).run_decoder(self, tgt, memory, memory_key_padding_mask)
+
+
+class _PointEmbedding(nn.Module):
+    def __init__(self, attr, fin, d):
+        super().__init__()
+        setattr(self, attr, _Linear(fin, d))
+
+
+class _SpectrumEmbedding(nn.Module):
+    def __init__(self, tag, fc, fin, d):
+        super().__init__()
+        setattr(self, "point_embedding_layer_" + tag, _PointEmbedding(fc, fin, d))
+        self._lin = ("point_embedding_layer_" + tag, fc)
+
+    def lin(self):
+        return getattr(getattr(self, self._lin[0]), self._lin[1])
+
+
+class _IREmbedding(nn.Module):
+    def __init__(self, bins, d):
+        super().__init__()
+        self.linear_spec_embedding_IR = _Linear(bins, d)
+
+
+class _TokenEmbedding(nn.Module):
+    def __init__(self, n, d):
+        super().__init__()
+        self.embedding = _Embedding(n, d, padding_idx=0)
+
+
+class _MWEmbedding(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.linear_spec_embedding_MW = _Linear(1, d)
+
+
+def _engine_of(mod):
+    eng = getattr(mod, "_mmst_engine", None)
+    if eng is None:
+        raise L.MMSTError("this submodule is not attached to a MultimodalTransformer")
+    return eng[0]
+
+
+def additive_mask(mask):
+    """torch.nn.functional.multi_head_attention_forward semantics for key_padding_mask: bool -> -inf on
+    True, anything else is added to the logits as it stands (the reference's int64/float masks)."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        return torch.zeros(mask.shape, dtype=torch.float32, device=mask.device).masked_fill(mask, float("-inf"))
+    return mask.to(torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+class _ForwardFn(torch.autograd.Function):
+    """Whole-model forward as ONE autograd node: backward runs the HIP backward chain and writes
+    the parameter gradients straight into the flat gradient buffer (param.grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, token, model, pl, outs):
+        ctx.model, ctx.pl = model, pl
+        ctx.mark_non_differentiable(outs[3])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dlogits, dfp, dmem, dmask):
+        model, pl = ctx.model, ctx.pl
+        eng = model._engine
+        if dlogits is None:
+            raise L.MMSTError("backward through the model needs a gradient on the logits")
+        # (T, B, V) fp32 -> internal [B*T][64] bf16
+        d = pl.cv.view(pl.dlogits, pl.B, pl.T, VPAD)
+        d.zero_()
+        d[:, :, :model.out_size] = dlogits.transpose(0, 1)
+        eng.arena.attach_grads(pl.mode)
+        eng.backward(pl, model.training)
+        return torch.zeros((), device=dlogits.device), None, None, None
+
+
+class MultimodalTransformer(nn.Module):
+    def __init__(self, config, src_pad_idx=0):
+        super().__init__()
+        self.config = config
+        d = config.hidden_size
+        if d != D:
+            raise ValueError("hidden_size must be 128 (the reference hard-codes it in its blank-modality branch)")
+        self.num_encoder_layers = config.num_encoder_layers
+        self.num_decoder_layers = config.num_decoder_layers
+        self.cross_heads = int(config.num_heads / 4)
+        if config.num_heads != 16:
+            raise ValueError("num_heads must be 16 (head_dim 8 / cross-encoder head_dim 32 kernels)")
+        self.out_size, self.max_len, self.fingerprint_size = config.out_size, config.max_len, config.fingerprint_size
+        self.linear_spec_embedding_1H = _SpectrumEmbedding("1H", "fc_H", config.input_dim_1H, d)
+        self.linear_spec_embedding_13C = _SpectrumEmbedding("13C", "fc_C", config.input_dim_13C, d)
+        self.linear_spec_embedding_HSQC = _SpectrumEmbedding("HSQC", "fc_HSQC", config.input_dim_HSQC, d)
+        self.linear_spec_embedding_COSY = _SpectrumEmbedding("COSY", "fc_COSY", config.input_dim_COSY, d)
+        self.linear_spec_embedding_IR = _IREmbedding(config.input_dim_IR, d)
+        self.linear_embedding_MF = _TokenEmbedding(config.MF_vocab_size, d)
+        self.linear_embedding_MS = _TokenEmbedding(config.MS_vocab_size, d)
+        self.linear_embedding_MW = _MWEmbedding(d)
+        self.embed_trg = _Embedding(config.in_size, d)
+        self.pe_trg = _Embedding(config.max_len, d)
+        self.encoder_1H = SpectralEncoder("1H", d, config.num_heads, config.num_encoder_layers)
+        self.encoder_13C = SpectralEncoder("13C", d, config.num_heads, config.num_encoder_layers)
+        self.encoder_HSQC = SpectralEncoder("HSQC", d, config.num_heads, config.num_encoder_layers)
+        self.encoder_COSY = SpectralEncoder("COSY", d, config.num_heads, config.num_encoder_layers)
+        self.encoder_IR = SpectralEncoder("IR", d, config.num_heads, config.num_encoder_layers)
+        self.encoder_cross = SpectralEncoder("cross", d, self.cross_heads, config.num_encoder_layers)
+        self.decoder = SmilesDecoder(d, config.num_heads, config.num_decoder_layers)
+        self.fp1 = _Linear(d, config.fingerprint_size)
+        self.dropout2 = nn.Dropout(config.drop_out)
+        self.fc_out = _Linear(d, config.out_size)
+        self.real_data_linear = _Linear(d, config.out_size)
+        object.__setattr__(self, "_engine", Engine(self))
+        holder = [self._engine]
+        for mod in self.modules():
+            object.__setattr__(mod, "_mmst_engine", holder)
+        self._grad_token = None
+        self._external_optimizer = True   # set False by the fused AdamW, which refreshes the bf16 copy itself
+        self.register_load_state_dict_post_hook(lambda module, keys: module._mark_stale())
+
+    # ------------------------------------------------------------------ housekeeping
+    def _mark_stale(self):
+        if self._engine.arena is not None:
+            self._engine.arena.shadow_stale = True
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._engine.arena = None   # storage moved: rebuild the arena on next use
+        return out
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        for k in list(sd.keys()):
+            sd[k] = sd[k].clone()   # contiguous copies, not views of the flat arena
+        return sd
+
+    def _dev(self):
+        return torch.device(self.config.device if getattr(self.config, "device", None) else "cuda")
+
+    # ------------------------------------------------------------------ reference helper surface
+    def _embed_spectrum(self, tag, spectrum, mask):
+        lin = getattr(self, "linear_spec_embedding_" + tag).lin()
+        x = spectrum.unsqueeze(-1) if tag == "13C" else spectrum
+        e = F.relu(F.linear(x.float(), lin.weight, lin.bias))
+        return e.permute(1, 0, 2), mask.to(torch.bool)
+
+    def _embed_spectrum_1H(self, spectrum, mask):
+        return self._embed_spectrum("1H", spectrum, mask)
+
+    def _embed_spectrum_13C(self, spectrum, mask):
+        return self._embed_spectrum("13C", spectrum, mask)
+
+    def _embed_spectrum_HSQC(self, spectrum, mask):
+        return self._embed_spectrum("HSQC", spectrum, mask)
+
+    def _embed_spectrum_COSY(self, spectrum, mask):
+        return self._embed_spectrum("COSY", spectrum, mask)
+
+    def _embed_spectrum_IR(self, spectrum, mask):
+        lin = self.linear_spec_embedding_IR.linear_spec_embedding_IR
+        e = F.relu(F.linear(spectrum.float(), lin.weight, lin.bias))
+        return e, torch.zeros(len(e), dtype=torch.bool, device=e.device)
+
+    def _embed_MF(self, tokenized_formula, padding_mask):
+        e = F.relu(self.linear_embedding_MF.embedding.weight[tokenized_formula])
+        return e.permute(1, 0, 2), padding_mask
+
+    def _embed_MS(self, tokenized_smi, padding_mask):
+        e = F.relu(self.linear_embedding_MS.embedding.weight[tokenized_smi])
+        return e.permute(1, 0, 2), padding_mask
+
+    def _embed_MW(self, trg_MW):
+        lin = self.linear_embedding_MW.linear_spec_embedding_MW
+        e = F.relu(F.linear(trg_MW.float(), lin.weight, lin.bias))
+        return e, torch.zeros((trg_MW.shape[0], 1), dtype=torch.bool, device=e.device)
+
+    def _cat(self, tag, e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW):
+        mode = self.config.training_mode
+        es, ms = [], []
+        for t, ee, mm in ((tag, e, m), ("MF", e_MF, m_MF), ("MS", e_MS, m_MS), ("MW", e_MW, m_MW)):
+            if t in mode and ee is not None:
+                es.append(ee)
+                ms.append(mm)
+        if es:
+            return torch.cat(es, dim=0), torch.cat(ms, dim=1)
+        print("No valid modes provided. Returning None.")
+        return None, None
+
+    def _create_embeddings_and_masks_1H(self, e=None, m=None, e_MF=None, m_MF=None, e_MS=None, m_MS=None,
+                                        e_MW=None, m_MW=None):
+        return self._cat("1H", e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW)
+
+    def _create_embeddings_and_masks_13C(self, e=None, m=None, e_MF=None, m_MF=None, e_MS=None, m_MS=None,
+                                         e_MW=None, m_MW=None):
+        return self._cat("13C", e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW)
+
+    def _create_embeddings_and_masks_HSQC(self, e=None, m=None, e_MF=None, m_MF=None, e_MS=None, m_MS=None,
+                                          e_MW=None, m_MW=None):
+        return self._cat("HSQC", e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW)
+
+    def _create_embeddings_and_masks_COSY(self, e=None, m=None, e_MF=None, m_MF=None, e_MS=None, m_MS=None,
+                                          e_MW=None, m_MW=None):
+        return self._cat("COSY", e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW)
+
+    def _create_embeddings_and_masks_IR(self, e=None, m=None, e_MF=None, m_MF=None, e_MS=None, m_MS=None,
+                                        e_MW=None, m_MW=None):
+        return self._cat("IR", e, m, e_MF, m_MF, e_MS, m_MS, e_MW, m_MW)
+
+    def generate_square_subsequent_mask(self, sz):
+        mask = (torch.triu(torch.ones(sz, sz)) == 1).transpose(0, 1)
+        mask = mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, float(0.0))
+        return mask.to(self._dev())
+
+    # ------------------------------------------------------------------ the hot path
+    def forward(self, src_1H, mask_1H, src_13C, mask_13C, src_HSQC, mask_HSQC, src_COSY, mask_COSY, src_IR, mask_IR,
+                src_MF, mask_MF, src_MS, mask_MS, trg_MW, trg_SMI_input=None):
+        batch = dict(src_1H=src_1H, mask_1H=mask_1H, src_13C=src_13C, mask_13C=mask_13C, src_HSQC=src_HSQC,
+                     mask_HSQC=mask_HSQC, src_COSY=src_COSY, mask_COSY=mask_COSY, src_IR=src_IR, mask_IR=mask_IR,
+                     src_MF=src_MF, mask_MF=mask_MF, src_MS=src_MS, mask_MS=mask_MS, trg_MW=trg_MW)
+        if trg_MW is None:
+            raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")  # as the reference (:804)
+        pl = self.run_encoder_half(batch, T=0 if trg_SMI_input is None else trg_SMI_input.shape[0])
+        memory, mask, fingerprint = self.outputs(pl)
+        if trg_SMI_input is None:
+            return memory, self._embedding_src(pl), mask, fingerprint
+        eng = self._engine
+        T, B = trg_SMI_input.shape
+        pl.cv.view(pl.tok, self.max_len + 1, B)[:T].copy_(trg_SMI_input)
+        eng.decode(pl, self.training, T=T)
+        logits = pl.cv.view(pl.logits, B, T, VPAD)[:, :, :self.out_size].transpose(0, 1)
+        if self.config.use_real_data:
+            raise L.MMSTError("use_real_data=True (real_data_linear averaging, :965-971) is not implemented")
+        outs = (logits, fingerprint, memory, mask)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self._grad_token is None or self._grad_token.device != logits.device:
+                self._grad_token = torch.zeros((), device=logits.device, requires_grad=True)
+            outs = _ForwardFn.apply(self._grad_token, self, pl, outs)
+        return outs
+
+    def run_encoder_half(self, batch, T=0):
+        """Embeddings + modality encoders + cross encoder + fingerprint; returns the plan that holds them."""
+        eng = self._engine
+        eng.ensure(self._dev())
+        mode = self.config.training_mode
+        first = next(batch["src_" + t] for t in ("1H", "13C", "HSQC", "COSY") if t in mode)
+        B = first.shape[0]
+        pl = eng.plan(B, T if T else 63, mode)
+        eng.encode(pl, batch, self.training)
+        return pl
+
+    def outputs(self, pl):
+        """(memory (L,B,128) fp32, src_padding_mask (B,L), fingerprint (B,512)) of an encoded plan."""
+        B, Lm = pl.B, pl.Lmem
+        memory = pl.cv.view(pl.memory, B, Lm, D).transpose(0, 1).float()
+        kb = pl.cv.view(pl.kbias_glob, B, Lm)
+        mask = torch.isinf(kb) if pl.mask_is_bool else kb.clone()
+        fingerprint = pl.cv.view(pl.fingerprint, B, self.fingerprint_size).clone()
+        return memory, mask, fingerprint
+
+    def _embedding_src(self, pl):
+        B, Lm = pl.B, pl.Lmem
+        out = torch.zeros(B, Lm, D, dtype=torch.float32, device=self._engine.device)
+        for name, S, off in pl.mods:
+            out[:, off:off + S] = pl.cv.view(pl.xseq[name], B, S, D).float()
+        return out.transpose(0, 1)
+
+    # fused loss path used by the training harness (no autograd graph at all)
+    def loss_and_backward(self, batch, on_segment=None, grad_scale=1.0):
+        """forward -> CE -> backward, entirely in HIP kernels.  Returns the loss as a device tensor [1]."""
+        eng = self._engine
+        trg = batch["trg_enc_SMI"]
+        T = trg.shape[1] - 1
+        pl = self.run_encoder_half(batch, T=T)
+        B = pl.B
+        pl.cv.view(pl.tok, self.max_len + 1, B)[:T].copy_(trg.to(eng.device).t()[:-1])
+        eng.decode(pl, self.training, T=T)
+        loss = eng.ce_loss(pl, trg, grad_scale=grad_scale)
+        eng.backward(pl, self.training, on_segment)
+        self._last_plan = pl
+        return loss
+
+
+# ---------------------------------------------------------------------------------------------
+# inference-only kernel-backed submodule calls (what run_model / the decode loops reach into)
+# ---------------------------------------------------------------------------------------------
+def _engine_linear(eng, lin, x):
+    eng.ensure(eng.model._dev())
+    ar = eng.arena
+    key = next(k for k, p in ar.named.items() if p is lin.weight)
+    N, K = lin.weight.shape
+    x2 = x.reshape(-1, K).to(torch.bfloat16).contiguous()
+    Np = VPAD if key in ("fc_out.weight", "real_data_linear.weight") else N
+    out = torch.empty(x2.shape[0], Np, dtype=torch.float32, device=x2.device)
+    ops.gemm([dict(P=x2, Q=ar.pb(key), C=out, bias=ar.p32(key[:-6] + "bias"), ldp=K, ldq=K, ldc=Np,
+                   Pn=x2.shape[0], Qn=Np, K=K, flags=L.GF_OUT_F32)], L.EPI_BIAS)
+    return out[:, :N].reshape(*x.shape[:-1], N)
+
+
+def _run_encoder(eng, enc, src, key_padding_mask):
+    import ctypes as C
+    if torch.is_grad_enabled() and enc.training:
+        raise L.MMSTError("submodule calls are inference-only; train through MultimodalTransformer.forward")
+    eng.ensure(eng.model._dev())
+    ar = eng.arena
+    S, B, _ = src.shape
+    x = src.transpose(0, 1).to(torch.bfloat16).contiguous()
+    kb = additive_mask(key_padding_mask)
+    kb = kb.contiguous() if kb is not None else None
+    M = B * S
+    bf, f32 = torch.bfloat16, torch.float32
+    dev = x.device
+    buf = dict(qkv=torch.empty(M, 3 * D, dtype=bf, device=dev), attn=torch.empty(M, D, dtype=bf, device=dev),
+               lse=torch.empty(B * enc.nhead * S, dtype=f32, device=dev), x1=torch.empty(M, D, dtype=bf, device=dev),
+               h=torch.empty(M, FF, dtype=bf, device=dev))
+    ys = [torch.empty(M, D, dtype=bf, device=dev) for _ in range(2)]
+    cur = x
+    for l in range(len(enc.layers)):
+        P_, G_ = (L.EncParams * 1)(), None
+        pfx = f"encoder_{enc.name_}.layers.{l}."
+        names = dict(w_qkv="self_attn.in_proj_weight", b_qkv="self_attn.in_proj_bias", w_o="self_attn.out_proj.weight",
+                     b_o="self_attn.out_proj.bias", w_1="linear1.weight", b_1="linear1.bias", w_2="linear2.weight",
+                     b_2="linear2.bias", g1="norm1.weight", be1="norm1.bias", g2="norm2.weight", be2="norm2.bias")
+        for f, k in names.items():
+            setattr(P_[0], f, ar.pb(pfx + k) if f.startswith("w_") else ar.p32(pfx + k))
+        A_ = (L.EncActs * 1)()
+        a = A_[0]
+        a.x, a.y = cur.data_ptr(), ys[l % 2].data_ptr()
+        a.kbias = kb.data_ptr() if kb is not None else None
+        a.qkv, a.attn, a.lse, a.x1, a.h = (buf[k].data_ptr() for k in ("qkv", "attn", "lse", "x1", "h"))
+        a.B, a.S = B, S
+        L.check(L.lib().mmst_encoder_layer_fwd(1, P_, A_, enc.nhead, C.c_float(0.0), C.c_uint32(0), L.stream_ptr()),
+                "mmst_encoder_layer_fwd")
+        cur = ys[l % 2]
+    return cur.view(B, S, D).transpose(0, 1).float()
+
+
+def _run_decoder(eng, dec, tgt, memory, memory_key_padding_mask):
+    import ctypes as C
+    if torch.is_grad_enabled() and dec.training:
+        raise L.MMSTError("submodule calls are inference-only; train through MultimodalTransformer.forward")
+    eng.ensure(eng.model._dev())
+    ar = eng.arena
+    T, B, _ = tgt.shape
+    Lm = memory.shape[0]
+    bf, f32 = torch.bfloat16, torch.float32
+    x = tgt.transpose(0, 1).to(bf).contiguous()
+    dev = x.device
+    # the memory's bf16 batch-first copy and its K/V projections are cached across the steps of a decode loop
+    cache = eng.__dict__.setdefault("_dec_cache", {})
+    ck = (memory.data_ptr(), tuple(memory.shape), memory._version, T > 1)
+    if cache.get("key", (None,))[:3] != ck[:3]:
+        cache.clear()
+        cache["key"] = ck
+        cache["mem"] = memory.transpose(0, 1).to(bf).contiguous()
+        mb = additive_mask(memory_key_padding_mask)
+        cache["mb"] = mb.contiguous() if mb is not None else None
+        cache["kvc"] = [torch.empty(B * Lm, 2 * D, dtype=bf, device=dev) for _ in dec.layers]
+        cache["ready"] = False
+    M = B * T
+    e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+    buf = dict(qkv=e(M, 3 * D), attn1=e(M, D), lse1=e(B * 16 * T, dt=f32), x1=e(M, D), qc=e(M, D), attn2=e(M, D),
+               lse2=e(B * 16 * T, dt=f32), x2=e(M, D), h=e(M, FF))
+    ys = [e(M, D), e(M, D)]
+    cur = x
+    names = dict(w_qkv="self_attn.in_proj_weight", b_qkv="self_attn.in_proj_bias", w_o="self_attn.out_proj.weight",
+                 b_o="self_attn.out_proj.bias", w_cqkv="multihead_attn.in_proj_weight",
+                 b_cqkv="multihead_attn.in_proj_bias", w_co="multihead_attn.out_proj.weight",
+                 b_co="multihead_attn.out_proj.bias", w_1="linear1.weight", b_1="linear1.bias",
+                 w_2="linear2.weight", b_2="linear2.bias", g1="norm1.weight", be1="norm1.bias",
+                 g2="norm2.weight", be2="norm2.bias", g3="norm3.weight", be3="norm3.bias")
+    for l in range(len(dec.layers)):
+        p = L.DecParams()
+        pfx = f"decoder.layers.{l}."
+        for f, k in names.items():
+            setattr(p, f, ar.pb(pfx + k) if f.startswith("w_") else ar.p32(pfx + k))
+        a = L.DecActs()
+        a.x, a.y = cur.data_ptr(), ys[l % 2].data_ptr()
+        a.mem = cache["mem"].data_ptr()
+        a.mem_bias = cache["mb"].data_ptr() if cache["mb"] is not None else None
+        for k in buf:
+            setattr(a, k, buf[k].data_ptr())
+        a.kvc = cache["kvc"][l].data_ptr()
+        a.kv_ready = int(cache["ready"])
+        a.B, a.T, a.L = B, T, Lm
+        L.check(L.lib().mmst_decoder_layer_fwd(C.byref(p), C.byref(a), 16, C.c_float(0.0), C.c_uint32(0),
+                                               L.stream_ptr()), "mmst_decoder_layer_fwd")
+        cur = ys[l % 2]
+    cache["ready"] = True
+    return cur.view(B, T, D).transpose(0, 1).float()
+
+
+Engine.linear = _engine_linear
+Engine.run_encoder = _run_encoder
+Engine.run_decoder = _run_decoder

@@ -1,0 +1,215 @@
+"""Training harness for the MI355X path: the counterpart of TransformerMultiGPU + run_training_MMT
+(utils_MMT/models_MMT_v15_4.py:985-1220, utils_MMT/MT_functions_v15_4.py:93-158) without
+pytorch_lightning: one process per GPU, per-rank batch = config.batch_size, CE loss on every
+position, AdamW(lr) + ReduceLROnPlateau(factor 0.5, patience 2), gradients averaged over ranks
+with RCCL all-reduce on contiguous tail segments of the flat gradient buffer while the earlier
+layers are still in backward.
+"""
+import ctypes as C
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import helper_functions as hf
+from .models_MMT import MultimodalTransformer
+
+
+def shard_indices(n, rank, world):
+    """DistributedSampler(shuffle=False, drop_last=False) sharding: pad the index list to a multiple of
+    `world` by wrapping around, then rank r takes r, r + world, ..."""
+    idx = list(range(n))
+    total = (n + world - 1) // world * world
+    idx += idx[: total - n]
+    return idx[rank:total:world]
+
+
+class GradReducer:
+    """Average a flat gradient buffer over ranks in contiguous segments, each all-reduce launched on a
+    side stream as soon as its segment is final (device tensors: RCCL; CPU tensors: gloo)."""
+
+    def __init__(self, flat, segments, world=None):
+        self.flat, self.segments = flat, segments
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.cuda = flat.is_cuda
+        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.works = []
+
+    def on_segment(self, name):
+        if self.world == 1:
+            return
+        lo, hi = self.segments[name]
+        view = self.flat[lo:hi]
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Wait for the segment reductions; the caller scales by 1/world (fused into the optimizer)."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return 1.0 / self.world
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) on the flat parameter
+    buffer, one kernel per contiguous run of active parameters; also refreshes the bf16 weights."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
+        self.step_count = 0
+        model._external_optimizer = False
+
+    def step(self, mode, grad_scale=1.0):
+        eng = self.model._engine
+        ar = eng.arena
+        if ar.M is None:
+            ar.M = torch.zeros_like(ar.P)
+            ar.V = torch.zeros_like(ar.P)
+        self.step_count += 1
+        st = L.stream_ptr()
+        for lo, hi in ar.active_ranges(mode):
+            L.check(L.lib().mmst_adamw(C.c_void_p(ar.P.data_ptr() + 4 * lo), C.c_void_p(ar.G.data_ptr() + 4 * lo),
+                                       C.c_void_p(ar.M.data_ptr() + 4 * lo), C.c_void_p(ar.V.data_ptr() + 4 * lo),
+                                       C.c_void_p(ar.Pb.data_ptr() + 2 * lo), C.c_long(hi - lo), C.c_float(self.lr),
+                                       C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                       C.c_float(self.wd), self.step_count, C.c_float(grad_scale), st), "mmst_adamw")
+
+    def zero_grad(self):
+        self.model._engine.arena.G.zero_()
+
+
+class ReduceLROnPlateau:
+    """mode='min', factor 0.5, patience 2 (models_MMT_v15_4.py:1215), threshold 1e-4 relative."""
+
+    def __init__(self, opt, factor=0.5, patience=2, threshold=1e-4):
+        self.opt, self.factor, self.patience, self.threshold = opt, factor, patience, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        if metric < self.best * (1 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            self.opt.lr *= self.factor
+            self.bad = 0
+
+
+class TransformerMultiGPU:
+    """Same role and attribute names as the reference's LightningModule wrapper."""
+
+    def __init__(self, config):
+        self.config = config
+        os.makedirs(config.model_save_dir, exist_ok=True)
+        self.model = MultimodalTransformer(config, src_pad_idx=0)
+        self.lr = config.lr_pretraining if config.training_setup == "pretraining" else config.lr_finetuning
+        self.itos = self.stoi = self.itos_MF = self.stoi_MF = None
+        for name in ("itos", "stoi", "itos_MF", "stoi_MF"):
+            path = getattr(config, name + "_path", None)
+            if path and os.path.exists(path):
+                setattr(self, name, json.load(open(path)))
+        self.optimizer = None
+        self.scheduler = None
+        self.reducer = None
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    def configure_optimizers(self):
+        self.optimizer = FusedAdamW(self.model, lr=self.lr)
+        self.scheduler = ReduceLROnPlateau(self.optimizer)
+        return self.optimizer
+
+    def forward(self, x):
+        mode = self.config.training_mode
+        g = lambda k, tag: x[k] if tag in mode else None  # noqa: E731
+        return self.model(g('src_1H', '1H'), g('mask_1H', '1H'), g('src_13C', '13C'), g('mask_13C', '13C'),
+                          g('src_HSQC', 'HSQC'), g('mask_HSQC', 'HSQC'), g('src_COSY', 'COSY'), g('mask_COSY', 'COSY'),
+                          g('src_IR', 'IR'), g('mask_IR', 'IR'), g('src_MF', 'MF'), g('mask_MF', 'MF'),
+                          g('src_MS', 'MS'), g('mask_MS', 'MS'), x['trg_MW'], x.get('trg_SMI_input'))
+
+    def training_step(self, x, batch_idx=0):
+        """One optimisation step: forward, CE (weight_SMI = 1, every other weight 0 in config_V8.json),
+        backward, gradient all-reduce, AdamW.  Returns {'loss': device tensor}."""
+        if self.optimizer is None:
+            self.configure_optimizers()
+        model, eng = self.model, self.model._engine
+        model.train()
+        eng.step_seed = (eng.step_seed * 1664525 + 1013904223) & 0xFFFFFFFF
+        eng.ensure(model._dev())
+        ar = eng.arena
+        if self.reducer is None or self.reducer.flat is not ar.G:
+            segs = {"decoder": (ar.marks["decoder"], ar.total), "cross": (ar.marks["cross"], ar.marks["decoder"]),
+                    "modal": (0, ar.marks["cross"])}
+            self.reducer = GradReducer(ar.G, segs, self.world)
+        ar.G.zero_()
+        loss = model.loss_and_backward(x, on_segment=self.reducer.on_segment)
+        scale = self.reducer.finish()
+        self.optimizer.step(self.config.training_mode, grad_scale=scale)
+        out = {'loss': loss}
+        if getattr(self.config, "gen_SMI_sequence", False):
+            from .generate import generate_sequences
+            pl = model._last_plan
+            out['gen'] = generate_sequences(model, pl, self.config, self.stoi, self.itos)
+            model.train()
+        return out
+
+    def validation_step(self, x, batch_idx=0):
+        self.model.eval()
+        with torch.no_grad():
+            x = dict(x)
+            trg = x['trg_enc_SMI'].to(self.model._dev()).t()
+            x['trg_SMI_input'] = trg[:-1, :]
+            logits, fp, memory, mask = self.forward(x)
+            pl = self.model._engine.plan(trg.shape[1], trg.shape[0] - 1, self.config.training_mode)
+            loss = self.model._engine.ce_loss(pl, x['trg_enc_SMI'], want_grad=False)
+        return {'loss': loss}
+
+    def on_epoch_end(self, epoch, loss):
+        path = os.path.join(self.config.model_save_dir, f"MultimodalTransformer_Epoch_{epoch}_Loss{loss:.3f}.pth")
+        torch.save(self.model.state_dict(), path)
+        return path
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, config=None):
+        """Reads the reference's .ckpt (Lightning dict, keys prefixed 'model.') or .pth (plain state_dict)
+        with a loader that executes nothing from the file."""
+        self = cls(config)
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        if "state_dict" in sd:
+            sd = {k[len("model."):]: v for k, v in sd["state_dict"].items() if k.startswith("model.")}
+        self.model.load_state_dict(sd)
+        return self
+
+
+def run_training_MMT(config, batches, num_epochs=None, log=print):
+    """Epoch loop of MT_functions_v15_4.py:93-158: `batches` is a callable epoch -> iterable of collated
+    batch dicts for THIS rank."""
+    tm = TransformerMultiGPU(config)
+    tm.to(config.device)
+    tm.configure_optimizers()
+    for epoch in range(num_epochs or config.num_epochs):
+        losses = []
+        for i, batch in enumerate(batches(epoch)):
+            losses.append(tm.training_step(batch, i)['loss'])
+        mean = float(torch.stack(losses).mean()) if losses else float("nan")
+        if dist.is_initialized():
+            t = torch.tensor([mean], device=config.device)
+            dist.all_reduce(t)
+            mean = float(t) / dist.get_world_size()
+        tm.scheduler.step(mean)
+        if config.save_model and (not dist.is_initialized() or dist.get_rank() == 0):
+            tm.on_epoch_end(epoch, mean)
+        log(f"epoch {epoch} loss {mean:.4f} lr {tm.optimizer.lr:g}")
+    return tm

@@ -17,8 +17,10 @@ def digest(t, n=96):
     return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
 
 
-def digest_close(got, want, rtol, atol):
-    """Compare two digests: the three moments relative to sum|x| / sum x^2, samples element-wise."""
+def digest_close(got, want, rtol, atol, outliers=0.0):
+    """Compare two digests: the three moments relative to sum|x| / sum x^2, samples element-wise.
+    `outliers` = fraction of samples allowed outside the tolerance (bf16 runs: the molecular-weight token
+    rows carry activations of several hundred, their attention rows are ill-conditioned in bf16)."""
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     scale = max(want[1], 1e-30)
@@ -27,4 +29,8 @@ def digest_close(got, want, rtol, atol):
     assert abs(got[2] - want[2]) <= 2 * rtol * max(want[2], 1e-30) + atol, ("sq-sum", got[2], want[2])
     # samples: tolerance relative to the tensor's own scale (largest sample), not to each element
     span = float(np.abs(want[3:]).max()) if want.size > 3 else 0.0
+    if outliers > 0:
+        bad = np.abs(got[3:] - want[3:]) > atol + rtol * span + rtol * np.abs(want[3:])
+        assert bad.mean() <= outliers, f"{bad.sum()} of {bad.size} samples out of tolerance"
+        return
     np.testing.assert_allclose(got[3:], want[3:], rtol=rtol, atol=atol + rtol * span)
