@@ -1,0 +1,147 @@
+"""Benchmark of the BASELINE.json metric: molecules/s of one TRAINING step (forward in train mode with
+dropout 0.1, cross-entropy on every position, backward, gradient all-reduce, AdamW) of the 4-modality
+MultimodalTransformer (config_V8.json architecture, training_mode 1H_HSQC_COSY_IR_MF_MW, 64 molecules per
+GPU), on N MI355X of one node, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODE = "1H_HSQC_COSY_IR_MF_MW"
+FLOP_PER_MOL_STEP = 28.08e9   # closed-form algorithmic work of one training step per molecule (3 x forward)
+
+
+def cpu_baseline(sample_b=8):
+    """The CPU oracle (port of the reference arithmetic) timed on the host cores on a bounded sample:
+    one training step (forward + CE + backward + AdamW, fp32) on `sample_b` molecules of the same workload."""
+    from oracle import mmt_oracle as O
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg = O.default_cfg(training_mode=MODE)
+    sd = O.make_state_dict(cfg, 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(x) for k, x in sd.items()}
+    batch = O.synthetic_batch(sample_b, 5, MODE)
+    t0 = time.time()
+    loss = O.training_forward(params, cfg, batch)[0]
+    loss.backward()
+    with torch.no_grad():
+        O.adamw_step(params, {k: p.grad for k, p in params.items()}, m, v, 1, cfg["lr_pretraining"])
+    dt = time.time() - t0
+    return {"value": sample_b / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step (fwd+CE+bwd+AdamW, fp32, no dropout) of the CPU oracle on {sample_b} "
+                      f"molecules, {MODE}, 6+6 layers; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen", action="store_true", help="also run the in-training greedy generation (secondary metric)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from oracle import mmt_oracle as O   # synthetic batch generator + config defaults only
+    from multimodalspectraltransformer_amd import _lib as L
+    from multimodalspectraltransformer_amd.train import TransformerMultiGPU
+
+    cfg = O.default_cfg(training_mode=MODE)
+    cfg.update(device=dev, training_setup="pretraining", lr_finetuning=5e-5, model_save_dir="/tmp/mmst_bench",
+               gen_SMI_sequence=bool(args.gen), sampling_method="greedy", batch_size=args.batch, save_model=False)
+    config = argparse.Namespace(**cfg)
+    torch.manual_seed(1234)
+    tm = TransformerMultiGPU(config).to(dev)
+    tm.configure_optimizers()
+    # synthetic, seeded, resident in HBM before the timed region; a few distinct batches per rank
+    batches = []
+    for i in range(4):
+        b = O.synthetic_batch(args.batch, 1000 + 17 * rank + i, MODE)
+        batches.append({k: v.to(dev) for k, v in b.items()})
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tm.training_step(batches[i % len(batches)], i)
+    sync()
+    lib = L.lib()
+    tap = hasattr(lib, "mmst_tap_reset")
+    if tap:
+        lib.mmst_tap_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = tm.training_step(batches[i % len(batches)], i)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    loss = float(out["loss"])
+
+    if rank == 0:
+        mols = world * args.batch * args.steps
+        res = {"metric": "molecules/sec training step (4-modality, seq<=128)", "value": mols / dt,
+               "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"training step, {MODE}, config_V8 architecture (6+6 layers, d=128, ff=2048), "
+                                      f"{args.batch} molecules/GPU, dropout 0.1, AdamW, "
+                                      f"gen_SMI_sequence={bool(args.gen)}",
+                          "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+               "final_loss": loss,
+               "model_tflops": mols * FLOP_PER_MOL_STEP / dt / 1e12}
+        if tap:
+            ms = C.c_float(0)
+            cnt = C.c_int(0)
+            flop = C.c_double(0)
+            byts = C.c_double(0)
+            name = C.create_string_buffer(128)
+            lib.mmst_tap_read(C.byref(ms), C.byref(cnt), C.byref(flop), C.byref(byts), name, 128)
+            if cnt.value > 0:
+                avg_s = ms.value / 1000.0 / cnt.value
+                bound = os.environ.get("MMST_TAP_BOUND", "hbm")
+                if bound == "hbm":
+                    a = byts.value / cnt.value / avg_s / 1e9
+                    res["roofline"] = {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": a / 8000.0, "traffic": None, "kernel": name.value.decode(),
+                                       "launches": cnt.value, "avg_us": avg_s * 1e6}
+                else:
+                    a = flop.value / cnt.value / avg_s / 1e12
+                    res["roofline"] = {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s",
+                                       "frac": a / 2500.0, "traffic": None, "kernel": name.value.decode(),
+                                       "launches": cnt.value, "avg_us": avg_s * 1e6}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

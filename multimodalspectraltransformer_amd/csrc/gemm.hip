@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   constexpr bool ROWEPI = (EPI == EPI_LN || EPI == EPI_LNBWD);
   constexpr int MT = ROWEPI ? 2 : 4;
   constexpr int NT = ROWEPI ? 8 : 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BP * BK * 2];
+  constexpr int SMEM = (EPI == EPI_ATOMIC) ? 4 * 32 * 65 * 4 : 2 * BP * BK * 2;  // images, or the atomic staging
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* Pimg = smem;
   unsigned char* Qimg = smem + BP * BK * 2;
 
@@ -153,8 +154,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     kbeg = (int)(((long)nk * ks_id) / pr.ksplit);
     kend = (int)(((long)nk * (ks_id + 1)) / pr.ksplit);
   }
-  float colsum = 0.f;
-  const bool do_colsum = (EPI == EPI_ATOMIC) && PT && pr.dbias != nullptr && qt == 0;
+  // bias gradient (column sums of the P-side operand over the contraction): one extra MFMA per
+  // P tile against an all-ones Q fragment, on the waves of wave-column 0 of Q-tile 0 only
+  const bool do_colsum = (EPI == EPI_ATOMIC) && PT && pr.dbias != nullptr && qt == 0 && (wave & 1) == 0;
+  f32x4 bacc[MT];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 
   if (kbeg < kend) {
     uint4 rp[4], rq[4];
@@ -168,16 +176,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
       if (kt + 1 < kend) {
         g2r<PT>(rp, pr.P, pr.ldp, p0, pr.Pn, (kt + 1) * BK, pr.K, tid);
         g2r<QT>(rq, pr.Q, pr.ldq, q0, pr.Qn, (kt + 1) * BK, pr.K, tid);
-      }
-      if (do_colsum && tid < 128) {
-        // column sums of the [64 c][128 p] image: bias gradient of the P-side operand
-        float s = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < BK; ++r) {
-          int off = r * 256 + (((tid >> 4) ^ fsw(r)) << 5) + (tid & 15) * 2;
-          s += (float)*reinterpret_cast<const bf16*>(Pimg + off);
-        }
-        colsum += s;
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -197,6 +195,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], acc[mt][nt], 0, 0, 0);
+        if (EPI == EPI_ATOMIC && do_colsum) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[mt], bacc[mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   const uint32_t thr = drop_threshold(pr.drop_p);
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
 
-  if constexpr (EPI == EPI_BIAS || EPI == EPI_DRELU || EPI == EPI_ATOMIC) {
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_DRELU) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = p0 + pw0 + mt * 16 + (lane & 15);
@@ -244,14 +247,48 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = r[e] > 0.f ? v[e] * dscale : 0.f;
           store8((bf16*)pr.C + (size_t)m * pr.ldc + n, v);
-        } else {
-          float* c = (float*)pr.C + (size_t)m * pr.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
         }
       }
     }
-    if (do_colsum && tid < 128 && p0 + tid < pr.Pn) atomicAdd(pr.dbias + p0 + tid, colsum);
+  }
+
+  if constexpr (EPI == EPI_ATOMIC) {
+    // Split-K accumulation into the fp32 gradient.  Float atomics only run at full rate when one
+    // wave-instruction covers 256 contiguous bytes, so each wave transposes its 64x64 sub-tile through
+    // LDS (two passes of 32 rows) and adds whole 64-float row segments.
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int mt = half * 2 + mh;
+        const int rl = mh * 16 + (lane & 15);
+#pragma unroll
+        for (int tp = 0; tp < NT / 2; ++tp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            stage[rl * 65 + tp * 32 + 8 * q + e] = acc[mt][2 * tp][e];
+            stage[rl * 65 + tp * 32 + 8 * q + 4 + e] = acc[mt][2 * tp + 1][e];
+          }
+      }
+      __syncthreads();
+      const int n = q0 + qw0 + lane;
+      if (n < pr.Qn) {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+          const int m = p0 + pw0 + half * 32 + r;
+          if (m < pr.Pn) atomicAdd((float*)pr.C + (size_t)m * pr.ldc + n, stage[r * 65 + lane]);
+        }
+      }
+    }
+    if (do_colsum && q == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = p0 + pw0 + mt * 16 + (lane & 15);
+        if (m < pr.Pn) atomicAdd(pr.dbias + m, bacc[mt][0]);
+      }
+    }
   }
 
   if constexpr (EPI == EPI_LN) {
