@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tap", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--gen", action="store_true", help="also run the in-training greedy generation (secondary metric)")
     args = ap.parse_args()
 
@@ -90,9 +91,11 @@ def main():
         tm.training_step(batches[i % len(batches)], i)
     sync()
     lib = L.lib()
-    tap = hasattr(lib, "mmst_tap_reset")
+    # time every launch of the dominant kernel (the split-K weight-gradient GEMM, see profiles/) with HIP
+    # events on its own stream during the timed steps
+    tap = rank == 0 and not args.no_tap
     if tap:
-        lib.mmst_tap_reset()
+        L.check(lib.mmst_tap_config(L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = tm.training_step(batches[i % len(batches)], i)
@@ -122,6 +125,7 @@ def main():
             flop = C.c_double(0)
             byts = C.c_double(0)
             name = C.create_string_buffer(128)
+            lib.mmst_tap_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
             lib.mmst_tap_read(C.byref(ms), C.byref(cnt), C.byref(flop), C.byref(byts), name, 128)
             if cnt.value > 0:
                 avg_s = ms.value / 1000.0 / cnt.value

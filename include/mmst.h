@@ -164,8 +164,9 @@ int mmst_seq_mean(const void* mem, void* out, int B, int L, void* stream);
  * row stride tok_ld */
 int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const float* pos, void* out, int B, int T,
                        float drop_p, uint32_t seed, void* stream);
+/* V = rows of the token table; gradients are ADDED to d_embed / d_pos (one workgroup owns each row). */
 int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
-                       float drop_p, uint32_t seed, void* stream);
+                       int V, float drop_p, uint32_t seed, void* stream);
 
 /* CrossEntropyLoss() over all B*T positions (:70, :268-271): logits fp32 [B*T][ldl] (first V columns valid),
  * target for row (b, t) = trg[b*trg_ld + t + 1].  Adds the mean loss to *loss and writes dlogits (bf16,

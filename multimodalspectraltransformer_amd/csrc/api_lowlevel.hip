@@ -3,6 +3,8 @@
 // projection and their gradients).  Structs are plain C (see gemm.h / attn.h).
 #include "attn.h"
 #include "gemm.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 extern "C" {
 
@@ -22,6 +24,48 @@ int mmst_attn_bwd(const AttnBatch* batch, void* stream) {
   if (!batch) return MMST_ERR_ARG;
   AttnBatch b = *batch;
   return launch_attn_bwd(b, (hipStream_t)stream);
+}
+
+// ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
+int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {
+  GemmTap& t = g_gemm_tap;
+  if (capacity > t.capacity) {
+    hipEvent_t* s = (hipEvent_t*)malloc(sizeof(hipEvent_t) * capacity);
+    hipEvent_t* e = (hipEvent_t*)malloc(sizeof(hipEvent_t) * capacity);
+    if (!s || !e) return MMST_ERR_ARG;
+    for (int i = 0; i < capacity; ++i) {
+      if (i < t.capacity) { s[i] = t.start[i]; e[i] = t.stop[i]; }
+      else if (hipEventCreate(&s[i]) != hipSuccess || hipEventCreate(&e[i]) != hipSuccess) return MMST_ERR_LAUNCH;
+    }
+    free(t.start); free(t.stop);
+    t.start = s; t.stop = e; t.capacity = capacity;
+  }
+  t.epi = epi; t.pt = p_contraction_major; t.qt = q_contraction_major;
+  t.count = 0; t.flops = 0.0; t.bytes = 0.0;
+  return MMST_OK;
+}
+
+int mmst_tap_reset() {
+  g_gemm_tap.count = 0; g_gemm_tap.flops = 0.0; g_gemm_tap.bytes = 0.0;
+  return MMST_OK;
+}
+
+// Sum of the timed launches' durations.  Synchronises on the last recorded event.
+int mmst_tap_read(float* total_ms, int* count, double* flops, double* bytes, char* name, int cap) {
+  GemmTap& t = g_gemm_tap;
+  float tot = 0.f;
+  if (t.count > 0 && hipEventSynchronize(t.stop[t.count - 1]) != hipSuccess) return MMST_ERR_LAUNCH;
+  for (int i = 0; i < t.count; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start[i], t.stop[i]) != hipSuccess) return MMST_ERR_LAUNCH;
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = t.count;
+  if (flops) *flops = t.flops;
+  if (bytes) *bytes = t.bytes;
+  if (name && cap > 0) snprintf(name, cap, "gemm_kernel<%d, %s, %s>", t.epi, t.pt ? "true" : "false", t.qt ? "true" : "false");
+  return MMST_OK;
 }
 
 int mmst_sizeof_gemm_batch() { return (int)sizeof(GemmBatch); }

@@ -44,5 +44,14 @@ struct GemmBatch {
   GemmProb p[GEMM_MAX_GROUPS];
 };
 
+// Diagnostic tap (bench.py): HIP events around every launch of ONE kernel variant, on the launch stream.
+struct GemmTap {
+  int epi, pt, qt;       // variant to time; epi < 0 = off
+  int count, capacity;
+  hipEvent_t* start; hipEvent_t* stop;
+  double flops, bytes;   // algorithmic work of the timed launches
+};
+extern GemmTap g_gemm_tap;
+
 // PT / QT: operand stored contraction-major.  Returns MMST_OK or an error code.
 int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream);

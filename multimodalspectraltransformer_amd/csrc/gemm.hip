@@ -466,6 +466,8 @@ int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
 
 }  // namespace
 
+GemmTap g_gemm_tap = {-1, 0, 0, 0, 0, nullptr, nullptr, 0.0, 0.0};
+
 int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
   if (b.n < 1 || b.n > GEMM_MAX_GROUPS) return MMST_ERR_ARG;
   int total = 0;
@@ -490,6 +492,18 @@ int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
     p.tile_begin = total;
     total += p.ptiles * p.qtiles * p.ksplit;
   }
+  GemmTap& tap = g_gemm_tap;
+  const bool timed = tap.epi == epi && tap.pt == (int)pt && tap.qt == (int)qt && tap.count < tap.capacity;
+  if (timed) {
+    for (int i = 0; i < b.n; ++i) {
+      const GemmProb& p = b.p[i];
+      const double out_bytes = (epi == EPI_ATOMIC) ? 8.0 : ((p.flags & GF_OUT_F32) ? 4.0 : 2.0);
+      tap.flops += 2.0 * p.Pn * (double)p.Qn * p.K;
+      tap.bytes += 2.0 * p.K * ((double)p.Pn + p.Qn) + out_bytes * p.Pn * (double)p.Qn +
+                   ((epi == EPI_DRELU || epi == EPI_LN) ? 2.0 * p.Pn * (double)p.Qn : 0.0);
+    }
+    hipEventRecord(tap.start[tap.count], stream);
+  }
   int rc;
   switch (epi) {
     case EPI_BIAS: rc = dispatch<EPI_BIAS>(b, pt, qt, total, stream); break;
@@ -499,6 +513,7 @@ int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
     case EPI_ATOMIC: rc = dispatch<EPI_ATOMIC>(b, pt, qt, total, stream); break;
     default: return MMST_ERR_ARG;
   }
+  if (timed) hipEventRecord(tap.stop[tap.count++], stream);
   if (rc != MMST_OK) return rc;
   MMST_CHECK_LAUNCH();
   return MMST_OK;

@@ -3,6 +3,7 @@
 #include "../../include/mmst.h"
 #include "attn.h"
 #include "gemm.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -16,11 +17,21 @@ inline GemmProb zero_prob() {
   return p;
 }
 
-// split-K factor for a weight-gradient GEMM: aim at >= 512 workgroups
+// split-K factor for a weight-gradient GEMM: enough workgroups to fill the chip, few enough that the
+// fp32 atomic traffic (ksplit x output bytes) stays small
+inline int ksplit_target() {
+  static int t = 0;
+  if (!t) {
+    const char* e = getenv("MMST_KSPLIT_TARGET");
+    t = e ? atoi(e) : 128;
+    if (t < 1) t = 128;
+  }
+  return t;
+}
 inline int pick_ksplit(int Pn, int Qn, int K) {
   int tiles = ((Pn + 127) / 128) * ((Qn + 127) / 128);
   int nk = (K + 63) / 64;
-  int s = (512 + tiles - 1) / tiles;
+  int s = (ksplit_target() + tiles - 1) / tiles;
   if (s > nk) s = nk;
   if (s < 1) s = 1;
   return s;

@@ -180,42 +180,61 @@ __global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, const float
   *reinterpret_cast<bf16x8*>(out + (size_t)row * D + c0) = o;
 }
 
+// Gradient of the two target-embedding tables without atomics: one workgroup per table row.
+// blocks [0, T)      : d_pos[t]  += sum over the batch of dout[b][t]
+// blocks [T, T + V)  : d_embed[v] += sum over every (b, t) whose token is v
 __global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16* dout, float* d_embed, float* d_pos,
-                                     int B, int T, float drop_p, uint32_t seed) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int row = gid >> 4, c0 = (gid & 15) * 8;
-  if (row >= B * T) return;
-  const int b = row / T, t = row % T;
-  const int64_t tk = tok[(size_t)t * tok_ld + b];
+                                     int B, int T, int V, float drop_p, uint32_t seed) {
+  const int c = threadIdx.x;
   const uint32_t thr = drop_threshold(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float g = (float)dout[(size_t)row * D + c0 + e];
-    if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c0 + e, thr) ? g * sc : 0.f;
-    atomicAdd(d_embed + (size_t)tk * D + c0 + e, g);
-    atomicAdd(d_pos + (size_t)t * D + c0 + e, g);
+  float acc = 0.f;
+  if ((int)blockIdx.x < T) {
+    const int t = blockIdx.x;
+    for (int b = 0; b < B; ++b) {
+      const int row = b * T + t;
+      float g = (float)dout[(size_t)row * D + c];
+      if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c, thr) ? g * sc : 0.f;
+      acc += g;
+    }
+    d_pos[(size_t)t * D + c] += acc;
+  } else {
+    const int v = blockIdx.x - T;
+    for (int t = 0; t < T; ++t)
+      for (int b = 0; b < B; ++b) {
+        if (tok[(size_t)t * tok_ld + b] != v) continue;
+        const int row = b * T + t;
+        float g = (float)dout[(size_t)row * D + c];
+        if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c, thr) ? g * sc : 0.f;
+        acc += g;
+      }
+    d_embed[(size_t)v * D + c] += acc;
   }
 }
 
-// one wave per row of logits (V <= 64)
+// one wave per row of logits (V <= 64), rows strided over the grid
 __global__ void ce_loss_kernel(const float* logits, int ldl, int V, const int64_t* trg, int trg_ld, int B, int T,
                                float* loss, bf16* dlogits, float grad_scale) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= B * T) return;
-  const int b = row / T, t = row % T;
-  const float x = lane < V ? logits[(size_t)row * ldl + lane] : -INFINITY;
-  const float mx = wave_max(x);
-  const float e = lane < V ? __expf(x - mx) : 0.f;
-  const float se = wave_sum(e);
-  const int target = (int)trg[(size_t)b * trg_ld + t + 1];
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
   const float inv_n = 1.0f / (float)(B * T);
-  if (lane == target) atomicAdd(loss, (mx + __logf(se) - x) * inv_n);
-  if (dlogits) {
-    float g = lane < V ? (e / se - (lane == target ? 1.f : 0.f)) * inv_n * grad_scale : 0.f;
-    dlogits[(size_t)row * 64 + lane] = (bf16)g;
+  float part = 0.f;
+  for (int row = wave; row < B * T; row += nwaves) {
+    const int b = row / T, t = row % T;
+    const float x = lane < V ? logits[(size_t)row * ldl + lane] : -INFINITY;
+    const float mx = wave_max(x);
+    const float e = lane < V ? __expf(x - mx) : 0.f;
+    const float se = wave_sum(e);
+    const int target = (int)trg[(size_t)b * trg_ld + t + 1];
+    if (lane == target) part += (mx + __logf(se) - x) * inv_n;
+    if (dlogits) {
+      float g = lane < V ? (e / se - (lane == target ? 1.f : 0.f)) * inv_n * grad_scale : 0.f;
+      dlogits[(size_t)row * 64 + lane] = (bf16)g;
+    }
   }
+  part = wave_sum(part);
+  if (lane == 0) atomicAdd(loss, part);
 }
 
 // softmax(logits / temperature) of the last position, first-index argmax, its probability
@@ -348,11 +367,10 @@ int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const
 }
 
 int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
-                       float drop_p, uint32_t seed, void* stream) {
-  if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1) return MMST_ERR_ARG;
-  const int threads = B * T * 16;
-  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
-                     (const bf16*)dout, d_embed, d_pos, B, T, drop_p, seed);
+                       int V, float drop_p, uint32_t seed, void* stream) {
+  if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1 || V < 1) return MMST_ERR_ARG;
+  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3(T + V), dim3(D), 0, (hipStream_t)stream, tok, tok_ld,
+                     (const bf16*)dout, d_embed, d_pos, B, T, V, drop_p, seed);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
@@ -361,7 +379,9 @@ int mmst_ce_loss(const float* logits, int ldl, int V, const int64_t* trg, int tr
                  void* dlogits, float grad_scale, void* stream) {
   if (!logits || !trg || !loss || V < 1 || V > 64 || B < 1 || T < 1 || trg_ld < T + 1) return MMST_ERR_ARG;
   const int rows = B * T;
-  hipLaunchKernelGGL(ce_loss_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, trg,
+  int blocks = (rows + 3) / 4;
+  if (blocks > 128) blocks = 128;
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, trg,
                      trg_ld, B, T, loss, (bf16*)dlogits, grad_scale);
   MMST_CHECK_LAUNCH();
   return MMST_OK;

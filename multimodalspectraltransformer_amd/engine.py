@@ -600,8 +600,8 @@ class Engine:
                                                st), "mmst_decoder_layer_bwd")
         L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
                                        C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
-                                       B, T, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)), st),
-                "mmst_trg_embed_bwd")
+                                       B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
+                                       st), "mmst_trg_embed_bwd")
         if on_segment:
             on_segment("decoder")
         # cross encoder

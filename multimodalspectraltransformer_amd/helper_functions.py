@@ -92,7 +92,7 @@ def tensor_to_smiles_and_prob_2(tensor, token_prob, itos):
             lens.append(n)
         return smiles, [token_prob[:n, i] for i, n in enumerate(lens)]
     smi = tensor_to_smiles(tensor, itos)
-    n = len(tokenize_smiles(smi)) if False else sum(1 for _ in _upto_eos(tensor, itos))
+    n = sum(1 for _ in _upto_eos(tensor, itos))
     return smi, token_prob[:n]
 
 
