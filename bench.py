@@ -23,7 +23,7 @@ MODE = "1H_HSQC_COSY_IR_MF_MW"
 FLOP_PER_MOL_STEP = 28.08e9   # closed-form algorithmic work of one training step per molecule (3 x forward)
 
 
-def cpu_baseline(sample_b=8):
+def cpu_baseline(sample_b=64, steps=2):
     """The CPU oracle (port of the reference arithmetic) timed on the host cores on a bounded sample:
     one training step (forward + CE + backward + AdamW, fp32) on `sample_b` molecules of the same workload."""
     from oracle import mmt_oracle as O
@@ -36,14 +36,32 @@ def cpu_baseline(sample_b=8):
     v = {k: torch.zeros_like(x) for k, x in sd.items()}
     batch = O.synthetic_batch(sample_b, 5, MODE)
     t0 = time.time()
-    loss = O.training_forward(params, cfg, batch)[0]
-    loss.backward()
-    with torch.no_grad():
-        O.adamw_step(params, {k: p.grad for k, p in params.items()}, m, v, 1, cfg["lr_pretraining"])
+    for step in range(1, steps + 1):
+        for p in params.values():
+            p.grad = None
+        loss = O.training_forward(params, cfg, batch)[0]
+        loss.backward()
+        with torch.no_grad():
+            O.adamw_step(params, {k: p.grad for k, p in params.items()}, m, v, step, cfg["lr_pretraining"])
     dt = time.time() - t0
-    return {"value": sample_b / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step (fwd+CE+bwd+AdamW, fp32, no dropout) of the CPU oracle on {sample_b} "
-                      f"molecules, {MODE}, 6+6 layers; {dt:.1f} s"}
+    return {"value": steps * sample_b / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps (fwd+CE+bwd+AdamW, fp32, no dropout) of the CPU oracle on {sample_b} "
+                      f"molecules each, {MODE}, 6+6 layers; {dt:.1f} s on {cores} threads"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of the same command
+    (profiles/*_hbm_traffic.json, written by tools/summarize_profile.py), newest round first; None if absent."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel):
+                return v["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -133,7 +151,9 @@ def main():
                 if bound == "hbm":
                     a = byts.value / cnt.value / avg_s / 1e9
                     res["roofline"] = {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s",
-                                       "frac": a / 8000.0, "traffic": None, "kernel": name.value.decode(),
+                                       "frac": a / 8000.0, "traffic": pmc_traffic(name.value.decode()),
+                                       "algorithmic_bytes_per_launch": byts.value / cnt.value,
+                                       "kernel": name.value.decode(),
                                        "launches": cnt.value, "avg_us": avg_s * 1e6}
                 else:
                     a = flop.value / cnt.value / avg_s / 1e12

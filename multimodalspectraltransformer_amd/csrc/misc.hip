@@ -180,35 +180,54 @@ __global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, const float
   *reinterpret_cast<bf16x8*>(out + (size_t)row * D + c0) = o;
 }
 
-// Gradient of the two target-embedding tables without atomics: one workgroup per table row.
+// Gradient of the two target-embedding tables without atomics: one workgroup per table row,
+// 8 row-groups x 128 columns per workgroup, token ids staged in LDS.
 // blocks [0, T)      : d_pos[t]  += sum over the batch of dout[b][t]
 // blocks [T, T + V)  : d_embed[v] += sum over every (b, t) whose token is v
 __global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16* dout, float* d_embed, float* d_pos,
                                      int B, int T, int V, float drop_p, uint32_t seed) {
-  const int c = threadIdx.x;
+  __shared__ short toks[8192];
+  __shared__ float red[8][D];
+  const int c = threadIdx.x & (D - 1), grp = threadIdx.x >> 7;
   const uint32_t thr = drop_threshold(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int rows = B * T;
   float acc = 0.f;
   if ((int)blockIdx.x < T) {
     const int t = blockIdx.x;
-    for (int b = 0; b < B; ++b) {
+    for (int b = grp; b < B; b += 8) {
       const int row = b * T + t;
       float g = (float)dout[(size_t)row * D + c];
       if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c, thr) ? g * sc : 0.f;
       acc += g;
     }
-    d_pos[(size_t)t * D + c] += acc;
   } else {
     const int v = blockIdx.x - T;
-    for (int t = 0; t < T; ++t)
-      for (int b = 0; b < B; ++b) {
-        if (tok[(size_t)t * tok_ld + b] != v) continue;
-        const int row = b * T + t;
+    for (int base = 0; base < rows; base += 8192) {
+      const int n = min(8192, rows - base);
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int row = base + i;
+        toks[i] = (short)tok[(size_t)(row % T) * tok_ld + row / T];
+      }
+      __syncthreads();
+      for (int i = grp; i < n; i += 8) {
+        if (toks[i] != v) continue;
+        const int row = base + i;
         float g = (float)dout[(size_t)row * D + c];
         if (drop_p > 0.f) g = drop_keep(seed, (uint32_t)row * D + c, thr) ? g * sc : 0.f;
         acc += g;
       }
-    d_embed[(size_t)v * D + c] += acc;
+    }
+  }
+  red[grp][c] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += red[i][c];
+    if ((int)blockIdx.x < T) d_pos[(size_t)blockIdx.x * D + c] += s;
+    else d_embed[(size_t)(blockIdx.x - T) * D + c] += s;
   }
 }
 
@@ -369,7 +388,7 @@ int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const
 int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
                        int V, float drop_p, uint32_t seed, void* stream) {
   if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1 || V < 1) return MMST_ERR_ARG;
-  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3(T + V), dim3(D), 0, (hipStream_t)stream, tok, tok_ld,
+  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3(T + V), dim3(8 * D), 0, (hipStream_t)stream, tok, tok_ld,
                      (const bf16*)dout, d_embed, d_pos, B, T, V, drop_p, seed);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
