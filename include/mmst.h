@@ -75,9 +75,17 @@ typedef struct {  /* backward state of ONE layer for ONE sequence group */
  * nn.TransformerEncoderLayer.forward as called from :846,:866,:886,:906,:927,:944. */
 int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
                            uint32_t seed, void* stream);
-/* Backward of the above (what autograd does for the reference). */
+/* Backward of the above (what autograd does for the reference) = _data followed by _weights. */
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                            const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+/* The two halves separately, so that a caller can put the parameter gradients on a second stream:
+ * _data    = critical path (activation gradients, LayerNorm affine gradients), leaves dh/dzd1/dqkv in w;
+ * _weights = every weight/bias gradient of the layer as one grouped split-K launch reading them.
+ * w's scratch must stay untouched until _weights has run. */
+int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
+                                   float drop_p, void* stream);
 
 /* ---- one post-norm decoder layer == nn.TransformerDecoderLayer(d_model=128, nhead=16) (:539-541) ---- */
 typedef struct {
@@ -106,6 +114,7 @@ typedef struct {
 typedef struct {
   const void* dz3; const void* dzd3;
   void* dh; void* dz2; void* dzd2; void* da; void* dqc; void* dkvc; void* dz1; void* dzd1; void* dqkv; float* delta;
+  void* da2;        /* scratch [B*T][128]: gradient at the cross-attention output */
   void* dmem;       /* [B*L][128] grad w.r.t. memory */
   int dmem_accumulate; /* 0: overwrite dmem, 1: add to it (layers after the first one processed) */
   void* dx; void* dxd;
@@ -120,6 +129,10 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
                            void* stream);
 int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
                            const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                                const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
+int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts* a, const mmst_dec_bwd* w,
+                                   float drop_p, void* stream);
 
 /* Standalone LayerNorm backward (top of a layer stack): dy -> dz / dzd, accumulates dgamma, dbeta.
  * dy row (b, s) is read at row b*dy_L + dy_off + s when dy_L > 0 (a slice of the concatenated memory). */

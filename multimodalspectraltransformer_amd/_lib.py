@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libmmst.so")
 
 EPI_BIAS, EPI_DRELU, EPI_LN, EPI_LNBWD, EPI_ATOMIC = range(5)
 GF_RELU, GF_OUT_F32 = 1, 2
-MAX_GROUPS = 6
+MAX_GROUPS = 6          # sequence groups per layer call / attention launch
+GEMM_MAX_GROUPS = 16    # problems per grouped GEMM launch
 
 
 class GemmProb(C.Structure):
@@ -32,7 +33,7 @@ class GemmProb(C.Structure):
 
 
 class GemmBatch(C.Structure):
-    _fields_ = [("n", C.c_int), ("p", GemmProb * MAX_GROUPS)]
+    _fields_ = [("n", C.c_int), ("p", GemmProb * GEMM_MAX_GROUPS)]
 
 
 class AttnProb(C.Structure):
@@ -132,7 +133,7 @@ class DecActs(C.Structure):
 
 class DecBwd(C.Structure):
     _fields_ = _ptrs("dz3", "dzd3", "dh", "dz2", "dzd2", "da", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta",
-                     "dmem") + [("dmem_accumulate", C.c_int)] + _ptrs(
+                     "da2", "dmem") + [("dmem_accumulate", C.c_int)] + _ptrs(
         "dx", "dxd", "prev_z3", "prev_st3", "prev_g3", "prev_dg3", "prev_dbe3") + [("prev_seed", C.c_uint32)]
 
 

@@ -13,6 +13,10 @@
 //     key on the lane, and P / dS feed dV^T += dO^T P and dK^T += Q^T dS.
 // head_dim 8 uses the same tiles with the contraction zero-padded to 16 (half of the
 // lanes supply zeros): the blocks are exp/VALU bound, the matrix pipe has slack.
+// A workgroup is 8 waves and covers a GROUP of heads whose columns are 128 contiguous bytes of every
+// token row (8 heads of 8, 2 heads of 32): the streamed chunk is staged with full-line coalesced loads
+// and every byte fetched from HBM is used (one (batch, head) per workgroup would fetch 16 B of each
+// 128 B line and pay 4-8x the traffic).  Wave w works on head (w % HG) and owner tile (w / HG).
 // Dropout on the attention probabilities is a counter hash of (b, h, q, key), so the
 // backward passes regenerate the forward's mask.
 #include "attn.h"
@@ -24,31 +28,35 @@ constexpr int TSTR = KC * 2 + 8;    // byte stride of a transposed-image row (==
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 
+constexpr int GC = 64;              // columns of a head group (= 128 bytes of a token row)
+constexpr int NWAVES = 8;
+
 template <int HD> struct Cfg {
   static constexpr int KS = HD == 32 ? 2 : 1;       // contraction steps over head_dim
-  static constexpr int RM_BYTES = KC * HD * 2;      // row-major image
-  static constexpr int TR_BYTES = HD * TSTR;        // transposed image
+  static constexpr int HG = GC / HD;                // heads per workgroup
+  static constexpr int TPB = NWAVES / HG;           // owner tiles per workgroup
+  static constexpr int RM_BYTES = KC * GC * 2;      // row-major image [KC][64]
+  static constexpr int TR_BYTES = GC * TSTR;        // transposed image [64][KC]
   static constexpr int OREGS = HD == 32 ? 16 : 4;   // valid accumulator registers of a d-major output
 };
 
 __device__ __forceinline__ int acc_row(int r16, int h) { return (r16 & 3) + 8 * (r16 >> 2) + 4 * h; }
 
-template <int HD>
-__device__ __forceinline__ int rm_off(int row, int ch) {
-  return HD == 32 ? row * 64 + ((ch ^ ((row >> 2) & 3)) << 4) : row * 16;
-}
+// 128-byte rows, 16-byte chunk ch XOR-swizzled so that the 16 rows of a ds_read_b128 lane group
+// (same chunk, rows r .. r+3 / r+12 .. / r+20 ..) fall on 16 different bank slots
+__device__ __forceinline__ int rm_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
-// Stage `nvalid` rows (zero-filled up to KC) of a [rows][HD] slice into a row-major
-// image and/or a transposed image.
-template <int HD, bool RM, bool TR>
+// Stage `nvalid` rows (zero-filled up to KC) of a [rows][64] head-group slice into a row-major
+// image and/or a transposed image.  8 consecutive lanes read one full 128-byte line.
+template <bool RM, bool TR>
 __device__ __forceinline__ void stage(unsigned char* rm, unsigned char* tr, const bf16* src, int ld, int nvalid,
                                       int tid, int nthr) {
-  constexpr int CPR = HD / 8;
+  constexpr int CPR = GC / 8;
   for (int c = tid; c < KC * CPR; c += nthr) {
     int row = c / CPR, ch = c % CPR;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < nvalid) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-    if (RM) *reinterpret_cast<uint4*>(rm + rm_off<HD>(row, ch)) = v;
+    if (RM) *reinterpret_cast<uint4*>(rm + rm_off(row, ch)) = v;
     if (TR) {
       const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
 #pragma unroll
@@ -67,19 +75,19 @@ __device__ __forceinline__ bf16x8 zero8() {
 
 // A operand (32 rows x 16 k) from a row-major image: lane (r, h) takes row `row`, k = 16 s + 8 h ..
 template <int HD>
-__device__ __forceinline__ bf16x8 afrag_rm(const unsigned char* img, int row, int s, int h) {
-  if (HD == 32) return *reinterpret_cast<const bf16x8*>(img + rm_off<32>(row, 2 * s + h));
-  bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 16);
+__device__ __forceinline__ bf16x8 afrag_rm(const unsigned char* img, int row, int s, int h, int hoff) {
+  if (HD == 32) return *reinterpret_cast<const bf16x8*>(img + rm_off(row, (hoff >> 3) + 2 * s + h));
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(img + rm_off(row, hoff >> 3));
   return h == 0 ? v : zero8();
 }
 
 // A operand (rows = d, k = 16 streamed rows from c0 + 16 s) from a transposed image, with k in the
 // order of an accumulator's rows: element j of lane half h is streamed row 16 s + 8 (j>>2) + 4 h + (j&3).
 template <int HD>
-__device__ __forceinline__ bf16x8 afrag_tr(const unsigned char* img, int c0, int s, int lane) {
+__device__ __forceinline__ bf16x8 afrag_tr(const unsigned char* img, int c0, int s, int lane, int hoff) {
   const int r = lane & 31, h = lane >> 5;
   const int d = HD == 32 ? r : (r & 7);
-  const unsigned char* p = img + d * TSTR + (c0 + 16 * s + 4 * h) * 2;
+  const unsigned char* p = img + (hoff + d) * TSTR + (c0 + 16 * s + 4 * h) * 2;
   s16x4 lo = *reinterpret_cast<const s16x4*>(p);
   s16x4 hi = *reinterpret_cast<const s16x4*>(p + 16);
   typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -128,7 +136,8 @@ __device__ __forceinline__ void store_rows(bf16* rowptr, const f32x16& acc, floa
   }
 }
 
-struct BlockCoord { int g, b, hh, blk; };
+struct BlockCoord { int g, b, hg, blk; };   // hg = head-group index
+template <int HD>
 __device__ __forceinline__ BlockCoord locate(const AttnBatch& batch) {
   int g = 0;
 #pragma unroll
@@ -136,12 +145,13 @@ __device__ __forceinline__ BlockCoord locate(const AttnBatch& batch) {
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].block_begin) g = i;
   const AttnProb& pr = batch.p[g];
   int local = blockIdx.x - pr.block_begin;
-  int bh = local / pr.blocks_per_bh;
+  int bg = local / pr.blocks_per_bh;
+  const int ngroups = pr.H / Cfg<HD>::HG;
   BlockCoord c;
   c.g = g;
   c.blk = local % pr.blocks_per_bh;
-  c.b = bh / pr.H;
-  c.hh = bh % pr.H;
+  c.b = bg / ngroups;
+  c.hg = bg % ngroups;
   return c;
 }
 
@@ -157,12 +167,14 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   unsigned char* Timg = smem + C::RM_BYTES * (BWD ? 2 : 1);    // fwd: V^T, bwd: K^T
   float* bias = reinterpret_cast<float*>(Timg + C::TR_BYTES);
 
-  const BlockCoord bc = locate(batch);
+  const BlockCoord bc = locate<HD>(batch);
   const AttnProb& pr = batch.p[bc.g];
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int b = bc.b, hh = bc.hh, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
-  const int q0 = (bc.blk * nw + wave) * 32;
+  const int hoff = (wave % C::HG) * HD;          // this wave's head inside the staged group
+  const int gcol = bc.hg * GC;                   // first column of the head group
+  const int b = bc.b, hh = bc.hg * C::HG + wave % C::HG, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const int q0 = (bc.blk * C::TPB + wave / C::HG) * 32;
   const bool active = q0 < Tq;
   const int q = q0 + r;
   const bool qvalid = active && q < Tq;
@@ -198,14 +210,14 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   for (int c0 = 0; c0 < Sk; c0 += KC) {
     const int nvalid = min(KC, Sk - c0);
     __syncthreads();
-    const bf16* ksrc = pr.K + (size_t)(b * Sk + c0) * pr.ldk + hh * HD;
-    const bf16* vsrc = pr.V + (size_t)(b * Sk + c0) * pr.ldv + hh * HD;
+    const bf16* ksrc = pr.K + (size_t)(b * Sk + c0) * pr.ldk + gcol;
+    const bf16* vsrc = pr.V + (size_t)(b * Sk + c0) * pr.ldv + gcol;
     if (!BWD) {
-      stage<HD, true, false>(Kimg, nullptr, ksrc, pr.ldk, nvalid, tid, nthr);
-      stage<HD, false, true>(nullptr, Timg, vsrc, pr.ldv, nvalid, tid, nthr);
+      stage<true, false>(Kimg, nullptr, ksrc, pr.ldk, nvalid, tid, nthr);
+      stage<false, true>(nullptr, Timg, vsrc, pr.ldv, nvalid, tid, nthr);
     } else {
-      stage<HD, true, true>(Kimg, Timg, ksrc, pr.ldk, nvalid, tid, nthr);
-      stage<HD, true, false>(Vimg, nullptr, vsrc, pr.ldv, nvalid, tid, nthr);
+      stage<true, true>(Kimg, Timg, ksrc, pr.ldk, nvalid, tid, nthr);
+      stage<true, false>(Vimg, nullptr, vsrc, pr.ldv, nvalid, tid, nthr);
     }
     for (int i = tid; i < KC; i += nthr) {
       float bv = -INFINITY;
@@ -221,7 +233,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
       f32x16 sacc = zero16();
 #pragma unroll
       for (int s = 0; s < C::KS; ++s)
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Kimg, lk0 + r, s, h), qf[s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Kimg, lk0 + r, s, h, hoff), qf[s], sacc, 0, 0, 0);
       float sv[16];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -261,7 +273,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
         f32x16 dpacc = zero16();
 #pragma unroll
         for (int s = 0; s < C::KS; ++s)
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Vimg, lk0 + r, s, h), dof[s], dpacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Vimg, lk0 + r, s, h, hoff), dof[s], dpacc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           float p0 = __builtin_amdgcn_exp2f(sv[i] - lse2), p1 = __builtin_amdgcn_exp2f(sv[i + 1] - lse2);
@@ -277,8 +289,8 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
         }
       }
       const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 0, lane), pf0, oacc, 0, 0, 0);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 1, lane), pf1, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 0, lane, hoff), pf0, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 1, lane, hoff), pf1, oacc, 0, 0, 0);
     }
   }
   if (!qvalid) return;
@@ -298,20 +310,23 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
 template <int HD, bool CAUSAL>
 __global__ void attn_kv_kernel(const AttnBatch batch) {
   typedef Cfg<HD> C;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 2 * KC * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 2 * C::HG * KC * 4];
   unsigned char* Qimg = smem;
   unsigned char* Dimg = smem + C::RM_BYTES;
   unsigned char* Qt = smem + 2 * C::RM_BYTES;
   unsigned char* Dt = Qt + C::TR_BYTES;
-  float* lse_s = reinterpret_cast<float*>(Dt + C::TR_BYTES);
-  float* del_s = lse_s + KC;
+  float* lse_all = reinterpret_cast<float*>(Dt + C::TR_BYTES);   // [HG][KC]
+  float* del_all = lse_all + C::HG * KC;
 
-  const BlockCoord bc = locate(batch);
+  const BlockCoord bc = locate<HD>(batch);
   const AttnProb& pr = batch.p[bc.g];
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int b = bc.b, hh = bc.hh, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
-  const int k0 = (bc.blk * nw + wave) * 32;
+  const int hl = wave % C::HG, hoff = hl * HD, gcol = bc.hg * GC;
+  const int b = bc.b, hh = bc.hg * C::HG + hl, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const float* lse_s = lse_all + hl * KC;
+  const float* del_s = del_all + hl * KC;
+  const int k0 = (bc.blk * C::TPB + wave / C::HG) * 32;
   const bool active = k0 < Sk;
   const int key = k0 + r;
   const bool kvalid = active && key < Sk;
@@ -333,16 +348,17 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   for (int c0 = 0; c0 < Tq; c0 += KC) {
     const int nvalid = min(KC, Tq - c0);
     __syncthreads();
-    stage<HD, true, true>(Qimg, Qt, pr.Q + (size_t)(b * Tq + c0) * pr.ldq + hh * HD, pr.ldq, nvalid, tid, nthr);
-    stage<HD, true, true>(Dimg, Dt, pr.dO + (size_t)(b * Tq + c0) * pr.lddo + hh * HD, pr.lddo, nvalid, tid, nthr);
-    for (int i = tid; i < KC; i += nthr) {
+    stage<true, true>(Qimg, Qt, pr.Q + (size_t)(b * Tq + c0) * pr.ldq + gcol, pr.ldq, nvalid, tid, nthr);
+    stage<true, true>(Dimg, Dt, pr.dO + (size_t)(b * Tq + c0) * pr.lddo + gcol, pr.lddo, nvalid, tid, nthr);
+    for (int j = tid; j < C::HG * KC; j += nthr) {
+      const int hj = j / KC, i = j % KC;
       float lv = 1.0e30f, dv = 0.f;
       if (i < nvalid) {
-        lv = pr.lse[(size_t)(b * H + hh) * Tq + c0 + i];
-        dv = pr.delta[(size_t)(b * H + hh) * Tq + c0 + i];
+        lv = pr.lse[(size_t)(b * H + bc.hg * C::HG + hj) * Tq + c0 + i];
+        dv = pr.delta[(size_t)(b * H + bc.hg * C::HG + hj) * Tq + c0 + i];
       }
-      lse_s[i] = lv;
-      del_s[i] = dv;
+      lse_all[j] = lv;
+      del_all[j] = dv;
     }
     __syncthreads();
     if (!active) continue;
@@ -353,8 +369,8 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
       f32x16 sacc = zero16(), dpacc = zero16();
 #pragma unroll
       for (int s = 0; s < C::KS; ++s) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Qimg, lq0 + r, s, h), kf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Dimg, lq0 + r, s, h), vf[s], dpacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Qimg, lq0 + r, s, h, hoff), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Dimg, lq0 + r, s, h, hoff), vf[s], dpacc, 0, 0, 0);
       }
       float pd[16], ds[16];
 #pragma unroll
@@ -383,10 +399,10 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
         }
       }
       const bf16x8 pf0 = pack8(pd), pf1 = pack8(pd + 8), sf0 = pack8(ds), sf1 = pack8(ds + 8);
-      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 0, lane), pf0, dvacc, 0, 0, 0);
-      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 1, lane), pf1, dvacc, 0, 0, 0);
-      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 0, lane), sf0, dkacc, 0, 0, 0);
-      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 1, lane), sf1, dkacc, 0, 0, 0);
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 0, lane, hoff), pf0, dvacc, 0, 0, 0);
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 1, lane, hoff), pf1, dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 0, lane, hoff), sf0, dkacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 1, lane, hoff), sf1, dkacc, 0, 0, 0);
     }
   }
   if (!kvalid) return;
@@ -394,20 +410,13 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
 }
 
-// waves per workgroup and workgroups per (batch, head) for `rows` owner rows
-void plan(const AttnBatch& b, bool owner_is_key, int& nw, int (&bpb)[ATTN_MAX_GROUPS]) {
-  nw = 1;
+// workgroups per (batch, head group): one per TPB owner tiles
+void plan(const AttnBatch& b, bool owner_is_key, int (&bpb)[ATTN_MAX_GROUPS]) {
+  const int tpb = b.hd == 32 ? Cfg<32>::TPB : Cfg<8>::TPB;
   for (int i = 0; i < b.n; ++i) {
     int rows = owner_is_key ? b.p[i].Sk : b.p[i].Tq;
     int tiles = (rows + 31) / 32;
-    int nblk = (tiles + 7) / 8;
-    int w = (tiles + nblk - 1) / nblk;
-    if (w > nw) nw = w;
-  }
-  for (int i = 0; i < b.n; ++i) {
-    int rows = owner_is_key ? b.p[i].Sk : b.p[i].Tq;
-    int tiles = (rows + 31) / 32;
-    bpb[i] = (tiles + nw - 1) / nw;
+    bpb[i] = (tiles + tpb - 1) / tpb;
   }
 }
 
@@ -417,6 +426,7 @@ int check(const AttnBatch& b) {
   for (int i = 0; i < b.n; ++i) {
     const AttnProb& p = b.p[i];
     if (p.B < 1 || p.H < 1 || p.Tq < 1 || p.Sk < 1) return MMST_ERR_ARG;
+    if (p.H % (GC / b.hd)) return MMST_ERR_ARG;   // heads come in groups of 128 bytes
     if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return MMST_ERR_ARG;
   }
   return MMST_OK;
@@ -424,15 +434,16 @@ int check(const AttnBatch& b) {
 
 template <bool BWD>
 int launch_q(AttnBatch& b, hipStream_t stream) {
-  int nw, bpb[ATTN_MAX_GROUPS];
-  plan(b, false, nw, bpb);
+  int bpb[ATTN_MAX_GROUPS];
+  plan(b, false, bpb);
+  const int hg = GC / b.hd;
   int total = 0;
   for (int i = 0; i < b.n; ++i) {
     b.p[i].blocks_per_bh = bpb[i];
     b.p[i].block_begin = total;
-    total += bpb[i] * b.p[i].B * b.p[i].H;
+    total += bpb[i] * b.p[i].B * (b.p[i].H / hg);
   }
-  dim3 grid(total), block(64 * nw);
+  dim3 grid(total), block(64 * NWAVES);
   if (b.hd == 32) {
     if (b.causal) hipLaunchKernelGGL((attn_q_kernel<32, true, BWD>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((attn_q_kernel<32, false, BWD>), grid, block, 0, stream, b);
@@ -461,15 +472,16 @@ int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {
   }
   rc = launch_q<true>(b, stream);
   if (rc) return rc;
-  int nw, bpb[ATTN_MAX_GROUPS];
-  plan(b, true, nw, bpb);
+  int bpb[ATTN_MAX_GROUPS];
+  plan(b, true, bpb);
+  const int hg = GC / b.hd;
   int total = 0;
   for (int i = 0; i < b.n; ++i) {
     b.p[i].blocks_per_bh = bpb[i];
     b.p[i].block_begin = total;
-    total += bpb[i] * b.p[i].B * b.p[i].H;
+    total += bpb[i] * b.p[i].B * (b.p[i].H / hg);
   }
-  dim3 grid(total), block(64 * nw);
+  dim3 grid(total), block(64 * NWAVES);
   if (b.hd == 32) {
     if (b.causal) hipLaunchKernelGGL((attn_kv_kernel<32, true>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((attn_kv_kernel<32, false>), grid, block, 0, stream, b);

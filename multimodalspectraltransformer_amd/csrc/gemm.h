@@ -38,7 +38,7 @@ struct GemmProb {
   int ptiles, qtiles;
 };
 
-#define GEMM_MAX_GROUPS 6
+#define GEMM_MAX_GROUPS 16
 struct GemmBatch {
   int n;
   GemmProb p[GEMM_MAX_GROUPS];

@@ -53,7 +53,7 @@ inline GemmProb wgrad(const void* dy, int M, int N, const void* x, int Kw, float
   p.Q = (const bf16*)x; p.ldq = Kw;
   p.C = dw; p.ldc = Kw; p.dbias = db;
   p.Pn = N; p.Qn = Kw; p.K = M;
-  p.ksplit = pick_ksplit(N, Kw, M);
+  p.ksplit = 1;  // set by launch_wgrads
   return p;
 }
 // dX[M,Kw] = dY[M,N] W[N,Kw]
@@ -64,6 +64,34 @@ inline GemmProb dgrad(const void* dy, int M, int N, const void* w, int Kw, void*
   p.C = dx; p.ldc = Kw;
   p.Pn = M; p.Qn = Kw; p.K = N;
   return p;
+}
+
+// All weight gradients of a layer in as few launches as the group limit allows.  The K split is chosen
+// so that every workgroup runs about the same number of 64-row contraction steps and the whole launch
+// has about ksplit_target() workgroups: small outputs then see a 10-20-way split (low atomic contention)
+// instead of one sized to fill the chip on their own.
+inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st) {
+  long work = 0;
+  for (int i = 0; i < np; ++i) {
+    long tiles = ((probs[i].Pn + 127) / 128) * (long)((probs[i].Qn + 127) / 128);
+    work += tiles * ((probs[i].K + 63) / 64);
+  }
+  int target = ksplit_target() * 4;
+  long iters = (work + target - 1) / target;
+  if (iters < 4) iters = 4;
+  for (int i = 0; i < np; ++i) {
+    int nk = (probs[i].K + 63) / 64;
+    int ks = (int)((nk + iters - 1) / iters);
+    probs[i].ksplit = ks < 1 ? 1 : ks;
+  }
+  for (int base = 0; base < np; base += GEMM_MAX_GROUPS) {
+    GemmBatch gb;
+    gb.n = np - base < GEMM_MAX_GROUPS ? np - base : GEMM_MAX_GROUPS;
+    for (int i = 0; i < gb.n; ++i) gb.p[i] = probs[base + i];
+    int rc = launch_gemm(gb, EPI_ATOMIC, true, true, st);
+    if (rc) return rc;
+  }
+  return MMST_OK;
 }
 
 #define RUN(expr)            \
@@ -131,16 +159,14 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
   return MMST_OK;
 }
 
-int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+// ---- encoder layer backward, critical path: gradients of activations only ----
+int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
   if (n < 1 || n > MMST_MAX_GROUPS || !p || !g || !a || !w || (nhead != 16 && nhead != 4)) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   const int hd = D / nhead;
   GemmBatch gb;
   gb.n = n;
-  // dW2, db2
-  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dzd2, a[i].B * a[i].S, D, a[i].h, FF, g[i].w_2, g[i].b_2);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   // dh = (dzd2 W2) * relu'/dropout mask
   for (int i = 0; i < n; ++i) {
     GemmProb q = dgrad(w[i].dzd2, a[i].B * a[i].S, D, p[i].w_2, FF, w[i].dh);
@@ -148,9 +174,6 @@ int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads
     gb.p[i] = q;
   }
   RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
-  // dW1, db1
-  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dh, a[i].B * a[i].S, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   // dx1 = dh W1 + dz2 -> norm1 backward
   for (int i = 0; i < n; ++i) {
     GemmProb q = dgrad(w[i].dh, a[i].B * a[i].S, FF, p[i].w_1, D, w[i].dz1);
@@ -162,12 +185,7 @@ int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads
     gb.p[i] = q;
   }
   RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
-  // dWo, dbo ; da = dzd1 Wo
-  for (int i = 0; i < n; ++i) {
-    const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
-    gb.p[i] = wgrad(dzd1, a[i].B * a[i].S, D, a[i].attn, D, g[i].w_o, g[i].b_o);
-  }
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
+  // da = dzd1 Wo
   for (int i = 0; i < n; ++i) {
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
     gb.p[i] = dgrad(dzd1, a[i].B * a[i].S, D, p[i].w_o, D, w[i].da);
@@ -190,9 +208,6 @@ int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads
     q.seed = seed + 8 * i + 0;
   }
   RUN(launch_attn_bwd(ab, st));
-  // dWqkv, dbqkv
-  for (int i = 0; i < n; ++i) gb.p[i] = wgrad(w[i].dqkv, a[i].B * a[i].S, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   // dx = dqkv Wqkv + dz1 ; fused with the previous layer's norm2 backward when there is one
   bool prev = w[0].prev_z2 != nullptr;
   for (int i = 0; i < n; ++i) {
@@ -209,6 +224,31 @@ int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads
   }
   RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
   return MMST_OK;
+}
+
+// ---- encoder layer backward, off the critical path: every parameter gradient of the layer as ONE grouped
+// split-K launch (all groups x {linear2, linear1, out_proj, in_proj}); reads what the data phase left in w ----
+int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
+                                   float drop_p, void* stream_) {
+  if (n < 1 || n > MMST_MAX_GROUPS || !g || !a || !w) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  GemmProb probs[4 * MMST_MAX_GROUPS];
+  int np = 0;
+  for (int i = 0; i < n; ++i) {
+    const int M = a[i].B * a[i].S;
+    const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
+    probs[np++] = wgrad(w[i].dzd2, M, D, a[i].h, FF, g[i].w_2, g[i].b_2);
+    probs[np++] = wgrad(w[i].dh, M, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+    probs[np++] = wgrad(dzd1, M, D, a[i].attn, D, g[i].w_o, g[i].b_o);
+    probs[np++] = wgrad(w[i].dqkv, M, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
+  }
+  return launch_wgrads(probs, np, st);
+}
+
+int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  RUN(mmst_encoder_layer_bwd_data(n, p, g, a, w, nhead, drop_p, seed, stream_));
+  return mmst_encoder_layer_bwd_weights(n, g, a, w, drop_p, stream_);
 }
 
 int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,
@@ -300,8 +340,9 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
   return MMST_OK;
 }
 
-int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
-                           const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+// ---- decoder layer backward, critical path ----
+int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                                const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
   if (!p || !g || !a || !w || nhead != 16) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   const int hd = D / nhead, M = a->B * a->T, ML = a->B * a->L;
@@ -309,16 +350,12 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
   GemmBatch gb;
   gb.n = 1;
   // feed-forward block
-  gb.p[0] = wgrad(w->dzd3, M, D, a->h, FF, g->w_2, g->b_2);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   {
     GemmProb q = dgrad(w->dzd3, M, D, p->w_2, FF, w->dh);
     q.R = (const bf16*)a->h; q.ldr = FF; q.drop_p = drop_p;
     gb.p[0] = q;
   }
   RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
-  gb.p[0] = wgrad(w->dh, M, FF, a->x2, D, g->w_1, g->b_1);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   {
     GemmProb q = dgrad(w->dh, M, FF, p->w_1, D, w->dz2);
     q.R = (const bf16*)w->dz3; q.ldr = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
@@ -329,9 +366,7 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
   RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
   const void* dzd2 = dr ? w->dzd2 : w->dz2;
   // cross-attention block
-  gb.p[0] = wgrad(dzd2, M, D, a->attn2, D, g->w_co, g->b_co);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
-  gb.p[0] = dgrad(dzd2, M, D, p->w_co, D, w->da);
+  gb.p[0] = dgrad(dzd2, M, D, p->w_co, D, w->da2);
   RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
   AttnBatch ab;
   memset(&ab, 0, sizeof(ab));
@@ -342,16 +377,11 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
     bf16* dkv = (bf16*)w->dkvc;
     q.Q = (const bf16*)a->qc; q.ldq = D; q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
     q.kbias = a->mem_bias; q.O = (bf16*)a->attn2; q.ldo = D; q.lse = a->lse2;
-    q.dO = (const bf16*)w->da; q.lddo = D; q.delta = w->delta;
+    q.dO = (const bf16*)w->da2; q.lddo = D; q.delta = w->delta;
     q.dQ = (bf16*)w->dqc; q.lddq = D; q.dK = dkv; q.dV = dkv + D; q.lddk = q.lddv = 2 * D;
     q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->L; q.seed = seed + 2;
   }
   RUN(launch_attn_bwd(ab, st));
-  gb.n = 2;
-  gb.p[0] = wgrad(w->dqc, M, D, a->x1, D, g->w_cqkv, g->b_cqkv);
-  gb.p[1] = wgrad(w->dkvc, ML, 2 * D, a->mem, D, g->w_cqkv + D * D, g->b_cqkv + D);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
-  gb.n = 1;
   {
     GemmProb q = dgrad(w->dkvc, ML, 2 * D, (const bf16*)p->w_cqkv + D * D, D, w->dmem);
     if (w->dmem_accumulate) { q.R = (const bf16*)w->dmem; q.ldr = D; }
@@ -368,8 +398,6 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
   RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
   const void* dzd1 = dr ? w->dzd1 : w->dz1;
   // self-attention block
-  gb.p[0] = wgrad(dzd1, M, D, a->attn1, D, g->w_o, g->b_o);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   gb.p[0] = dgrad(dzd1, M, D, p->w_o, D, w->da);
   RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
   ab.causal = 1;
@@ -385,8 +413,6 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
     q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->T; q.seed = seed + 0;
   }
   RUN(launch_attn_bwd(ab, st));
-  gb.p[0] = wgrad(w->dqkv, M, 3 * D, a->x, D, g->w_qkv, g->b_qkv);
-  RUN(launch_gemm(gb, EPI_ATOMIC, true, true, st));
   {
     GemmProb q = dgrad(w->dqkv, M, 3 * D, p->w_qkv, D, w->dx);
     q.R = (const bf16*)w->dz1; q.ldr = D;
@@ -400,6 +426,31 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
     RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
   }
   return MMST_OK;
+}
+
+// ---- decoder layer backward, parameter gradients: one grouped split-K launch ----
+int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts* a, const mmst_dec_bwd* w,
+                                   float drop_p, void* stream_) {
+  if (!g || !a || !w) return MMST_ERR_ARG;
+  const int M = a->B * a->T, ML = a->B * a->L;
+  const bool dr = drop_p > 0.f;
+  const void* dzd2 = dr ? w->dzd2 : w->dz2;
+  const void* dzd1 = dr ? w->dzd1 : w->dz1;
+  GemmProb probs[7];
+  probs[0] = wgrad(w->dzd3, M, D, a->h, FF, g->w_2, g->b_2);
+  probs[1] = wgrad(w->dh, M, FF, a->x2, D, g->w_1, g->b_1);
+  probs[2] = wgrad(dzd2, M, D, a->attn2, D, g->w_co, g->b_co);
+  probs[3] = wgrad(w->dqc, M, D, a->x1, D, g->w_cqkv, g->b_cqkv);
+  probs[4] = wgrad(w->dkvc, ML, 2 * D, a->mem, D, g->w_cqkv + D * D, g->b_cqkv + D);
+  probs[5] = wgrad(dzd1, M, D, a->attn1, D, g->w_o, g->b_o);
+  probs[6] = wgrad(w->dqkv, M, 3 * D, a->x, D, g->w_qkv, g->b_qkv);
+  return launch_wgrads(probs, 7, (hipStream_t)stream_);
+}
+
+int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                           const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  RUN(mmst_decoder_layer_bwd_data(p, g, a, w, nhead, drop_p, seed, stream_));
+  return mmst_decoder_layer_bwd_weights(g, a, w, drop_p, stream_);
 }
 
 }  // extern "C"

@@ -243,16 +243,22 @@ class Plan:
         self.loss = cv.take(1, f32)
         self.next_prob = cv.take((m.max_len + 1) * B, f32)
 
-        # backward scratch
+        # backward scratch: one set PER LAYER, never reused inside a step, so the weight-gradient launches
+        # can run on a second stream with no write-after-read hazards (HBM is not the scarce resource here)
         def bwd_scratch(Mr, Hh, S_):
             return dict(dh=cv.take(Mr * FF), dz1=cv.take(Mr * D), dzd1=cv.take(Mr * D), da=cv.take(Mr * D),
                         dqkv=cv.take(Mr * 3 * D), delta=cv.take(B * Hh * S_, f32),
-                        dzA=cv.take(Mr * D), dzdA=cv.take(Mr * D), dzB=cv.take(Mr * D), dzdB=cv.take(Mr * D))
+                        dz=cv.take(Mr * D), dzd=cv.take(Mr * D))
 
-        self.modal_bwd = [bwd_scratch(B * S, 16, S) for _, S, _ in self.mods]
-        self.cross_bwd = bwd_scratch(B * Lm, 4, Lm)
-        self.dec_bwd = bwd_scratch(M, 16, max(Tm, 1))
-        self.dec_bwd.update(dz2=cv.take(M * D), dzd2=cv.take(M * D), dqc=cv.take(M * D), dkvc=cv.take(B * Lm * 2 * D))
+        self.modal_bwd = [[bwd_scratch(B * S, 16, S) for _, S, _ in self.mods] for _ in range(nl)]
+        self.dxseq = [cv.take(B * S * D) for _, S, _ in self.mods]
+        self.cross_bwd = [bwd_scratch(B * Lm, 4, Lm) for _ in range(nl)]
+        self.dec_bwd = []
+        for _ in range(ndl):
+            sc = bwd_scratch(M, 16, max(Tm, 1))
+            sc.update(dz2=cv.take(M * D), dzd2=cv.take(M * D), dqc=cv.take(M * D), da2=cv.take(M * D),
+                      dkvc=cv.take(B * Lm * 2 * D))
+            self.dec_bwd.append(sc)
         self.dmem = cv.take(B * Lm * D)
         self.dmem_in = cv.take(B * Lm * D)
         self.dtrg = cv.take(M * D)
@@ -317,14 +323,15 @@ class Plan:
                 for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
                     setattr(a, f, _P(acts[f]))
                 a.B, a.S = B, S
-                w, sc = W_[i], self.modal_bwd[i]
-                # dz buffers alternate between layers: layer l reads slot (l % 2), writes slot ((l-1) % 2)
-                rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
-                w.dz2, w.dzd2 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+                w, sc = W_[i], self.modal_bwd[l][i]
+                w.dz2, w.dzd2 = _P(sc["dz"]), _P(sc["dzd"])
                 self.modal_dzd[l].append((w.dz2, w.dzd2))
                 for f in ("dh", "dz1", "dzd1", "da", "dqkv", "delta"):
                     setattr(w, f, _P(sc[f]))
-                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                if l > 0:
+                    w.dx, w.dxd = _P(self.modal_bwd[l - 1][i]["dz"]), _P(self.modal_bwd[l - 1][i]["dzd"])
+                else:
+                    w.dx = _P(self.dxseq[i])
                 if l > 0:
                     pa = self.modal_acts[l - 1][i]
                     pk = f"encoder_{name}.layers.{l - 1}."
@@ -344,14 +351,13 @@ class Plan:
             for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
                 setattr(a, f, _P(acts[f]))
             a.B, a.S = B, Lm
-            w, sc = W_[0], self.cross_bwd
-            rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
-            w.dz2, w.dzd2 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+            w, sc = W_[0], self.cross_bwd[l]
+            w.dz2, w.dzd2 = _P(sc["dz"]), _P(sc["dzd"])
             self.cross_dzd.append((w.dz2, w.dzd2))
             for f in ("dh", "dz1", "dzd1", "da", "dqkv", "delta"):
                 setattr(w, f, _P(sc[f]))
             if l > 0:
-                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                w.dx, w.dxd = _P(self.cross_bwd[l - 1]["dz"]), _P(self.cross_bwd[l - 1]["dzd"])
                 pa, pk = self.cross_acts[l - 1], f"encoder_cross.layers.{l - 1}."
                 w.prev_z2, w.prev_st2 = _P(pa["z2"]), _P(pa["st2"])
                 w.prev_g2 = ar.p32(pk + "norm2.weight")
@@ -373,16 +379,15 @@ class Plan:
                       "z3", "st3"):
                 setattr(a, f, _P(acts[f]))
             a.B, a.T, a.L = B, T, Lm
-            w, sc = L.DecBwd(), self.dec_bwd
-            rd, wr = ("A", "B") if l % 2 == 0 else ("B", "A")
-            w.dz3, w.dzd3 = _P(sc["dz" + rd]), _P(sc["dzd" + rd])
+            w, sc = L.DecBwd(), self.dec_bwd[l]
+            w.dz3, w.dzd3 = _P(sc["dz"]), _P(sc["dzd"])
             self.dec_dzd.append((w.dz3, w.dzd3))
-            for f in ("dh", "dz2", "dzd2", "da", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta"):
+            for f in ("dh", "dz2", "dzd2", "da", "da2", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta"):
                 setattr(w, f, _P(sc[f]))
             w.dmem = _P(self.dmem)
             w.dmem_accumulate = 0 if l == ndl - 1 else 1
             if l > 0:
-                w.dx, w.dxd = _P(sc["dz" + wr]), _P(sc["dzd" + wr])
+                w.dx, w.dxd = _P(self.dec_bwd[l - 1]["dz"]), _P(self.dec_bwd[l - 1]["dzd"])
                 pa, pk = self.dec_acts[l - 1], f"decoder.layers.{l - 1}."
                 w.prev_z3, w.prev_st3 = _P(pa["z3"]), _P(pa["st3"])
                 w.prev_g3 = ar.p32(pk + "norm3.weight")
@@ -570,34 +575,55 @@ class Engine:
     # ------------------------------------------------------------------
     def backward(self, pl, train, on_segment=None):
         """Backward of decode() + encode() from pl.dlogits; accumulates into the flat gradient buffer.
-        on_segment(name) is called when the gradient memory of 'decoder', 'cross', 'modal' is final."""
-        lib, st, ar, B, T, Lm = L.lib(), L.stream_ptr(), self.arena, pl.B, pl.T, pl.Lmem
+
+        Two streams: the critical path (activation gradients) runs on the current stream; each layer's
+        parameter gradients (one grouped split-K launch) run on a second stream as soon as that layer's
+        data phase is done, filling the CUs the small critical-path launches leave idle.
+        on_segment(name) is called when the launches that finish the gradient memory of 'decoder',
+        'cross', 'modal' have been ENQUEUED; self.wstream then holds the last of them."""
+        lib, ar, B, T, Lm = L.lib(), self.arena, pl.B, pl.T, pl.Lmem
         m = self.model
         nl, ndl = m.num_encoder_layers, m.num_decoder_layers
         p_drop = LAYER_DROPOUT if train else 0.0
         p_drop2 = float(m.config.drop_out) if train else 0.0
         M = B * T
+        main = torch.cuda.current_stream()
+        if getattr(self, "wstream", None) is None or self.wstream.device != main.device:
+            self.wstream = torch.cuda.Stream(device=main.device)
+        ws = self.wstream
+        st, wst = C.c_void_p(main.cuda_stream), C.c_void_p(ws.cuda_stream)
+        ws.wait_stream(main)   # gradients were zeroed / forward finished on the main stream
+
+        def weights_after_data():
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ws.wait_event(ev)
+
         # vocabulary projection
         last = pl.dec_acts[ndl - 1]
-        ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
-                       ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(64, M // 64)))],
-                 L.EPI_ATOMIC, pt=True, qt=True)
-        sc = pl.dec_bwd
-        rd = "A" if (ndl - 1) % 2 == 0 else "B"
-        ops.gemm([dict(P=_P(pl.dlogits), Q=ar.pb("fc_out.weight"), C=_P(sc["dz" + rd]),
-                       C2=_P(sc["dzd" + rd]) if p_drop > 0 else None, Z=_P(last["z3"]), stats=_P(last["st3"]),
+        sc = pl.dec_bwd[ndl - 1]
+        ops.gemm([dict(P=_P(pl.dlogits), Q=ar.pb("fc_out.weight"), C=_P(sc["dz"]),
+                       C2=_P(sc["dzd"]) if p_drop > 0 else None, Z=_P(last["z3"]), stats=_P(last["st3"]),
                        gamma=ar.p32(f"decoder.layers.{ndl - 1}.norm3.weight"),
                        dgamma=ar.g32(f"decoder.layers.{ndl - 1}.norm3.weight"),
                        dbeta=ar.g32(f"decoder.layers.{ndl - 1}.norm3.bias"),
                        ldp=VPAD, ldq=D, ldc=D, Pn=M, Qn=D, K=VPAD, drop_p=p_drop,
                        seed=(self.layer_seed(64 + ndl - 1) + 5) & 0xFFFFFFFF)], L.EPI_LNBWD, qt=True)
+        with torch.cuda.stream(ws):
+            ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
+                           ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(16, M // 256)))],
+                     L.EPI_ATOMIC, pt=True, qt=True)
         for l in reversed(range(ndl)):
             w = pl.dec_w[l]
             w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
             w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
-            L.check(lib.mmst_decoder_layer_bwd(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
-                                               C.byref(w), 16, C.c_float(p_drop), C.c_uint32(self.layer_seed(64 + l)),
-                                               st), "mmst_decoder_layer_bwd")
+            L.check(lib.mmst_decoder_layer_bwd_data(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
+                                                    C.byref(w), 16, C.c_float(p_drop),
+                                                    C.c_uint32(self.layer_seed(64 + l)), st),
+                    "mmst_decoder_layer_bwd_data")
+            weights_after_data()
+            L.check(lib.mmst_decoder_layer_bwd_weights(C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]), C.byref(w),
+                                                       C.c_float(p_drop), wst), "mmst_decoder_layer_bwd_weights")
         L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
                                        C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
                                        B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
@@ -605,31 +631,33 @@ class Engine:
         if on_segment:
             on_segment("decoder")
         # cross encoder
-        sc = pl.cross_bwd
-        rd = "A" if (nl - 1) % 2 == 0 else "B"
+        sc = pl.cross_bwd[nl - 1]
         lastc = pl.cross_acts[nl - 1]
         pk = f"encoder_cross.layers.{nl - 1}."
         L.check(lib.mmst_layernorm_bwd(B * Lm, C.c_void_p(_P(pl.dmem)), 0, 0, 0, C.c_void_p(_P(lastc["z2"])),
                                        C.c_void_p(_P(lastc["st2"])), C.c_void_p(ar.p32(pk + "norm2.weight")),
-                                       C.c_void_p(_P(sc["dz" + rd])), C.c_void_p(_P(sc["dzd" + rd])),
+                                       C.c_void_p(_P(sc["dz"])), C.c_void_p(_P(sc["dzd"])),
                                        C.c_void_p(ar.g32(pk + "norm2.weight")), C.c_void_p(ar.g32(pk + "norm2.bias")),
                                        C.c_float(p_drop), C.c_uint32((self.layer_seed(32 + nl - 1) + 3) & 0xFFFFFFFF),
                                        st), "mmst_layernorm_bwd")
         for l in reversed(range(nl)):
             pl.cross_w[l][0].prev_seed = self.layer_seed(32 + l - 1) if l > 0 else 0
             pl.cross_w[l][0].dzd2 = pl.cross_dzd[l][1] if p_drop > 0 else pl.cross_dzd[l][0]
-            L.check(lib.mmst_encoder_layer_bwd(1, pl.cross_p[l], pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
-                                               m.cross_heads, C.c_float(p_drop), C.c_uint32(self.layer_seed(32 + l)),
-                                               st), "mmst_encoder_layer_bwd")
+            L.check(lib.mmst_encoder_layer_bwd_data(1, pl.cross_p[l], pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
+                                                    m.cross_heads, C.c_float(p_drop),
+                                                    C.c_uint32(self.layer_seed(32 + l)), st),
+                    "mmst_encoder_layer_bwd_data")
+            weights_after_data()
+            L.check(lib.mmst_encoder_layer_bwd_weights(1, pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
+                                                       C.c_float(p_drop), wst), "mmst_encoder_layer_bwd_weights")
         if on_segment:
             on_segment("cross")
         # modality encoders: top LayerNorm backward reads its slice of d(memory_in)
-        rd = "A" if (nl - 1) % 2 == 0 else "B"
         groups = []
         for i, (name, S, off) in enumerate(pl.mods):
-            acts, scm = pl.modal_acts[nl - 1][i], pl.modal_bwd[i]
+            acts, scm = pl.modal_acts[nl - 1][i], pl.modal_bwd[nl - 1][i]
             pk = f"encoder_{name}.layers.{nl - 1}."
-            groups.append(dict(C=_P(scm["dz" + rd]), C2=_P(scm["dzd" + rd]) if p_drop > 0 else None,
+            groups.append(dict(C=_P(scm["dz"]), C2=_P(scm["dzd"]) if p_drop > 0 else None,
                                R=_P(pl.dmem_in), ldr=D, rS=S, rL=Lm, roff=off, Z=_P(acts["z2"]), stats=_P(acts["st2"]),
                                gamma=ar.p32(pk + "norm2.weight"), dgamma=ar.g32(pk + "norm2.weight"),
                                dbeta=ar.g32(pk + "norm2.bias"), ldp=8, ldq=8, ldc=D, Pn=B * S, Qn=D, K=0,
@@ -639,13 +667,16 @@ class Engine:
             for i in range(pl.n_groups):
                 pl.modal_w[l][i].prev_seed = self.layer_seed(l - 1) if l > 0 else 0
                 pl.modal_w[l][i].dzd2 = pl.modal_dzd[l][i][1] if p_drop > 0 else pl.modal_dzd[l][i][0]
-            L.check(lib.mmst_encoder_layer_bwd(pl.n_groups, pl.modal_p[l], pl.modal_g[l], pl.modal_a[l], pl.modal_w[l],
-                                               16, C.c_float(p_drop), C.c_uint32(self.layer_seed(l)), st),
-                    "mmst_encoder_layer_bwd")
+            L.check(lib.mmst_encoder_layer_bwd_data(pl.n_groups, pl.modal_p[l], pl.modal_g[l], pl.modal_a[l],
+                                                    pl.modal_w[l], 16, C.c_float(p_drop),
+                                                    C.c_uint32(self.layer_seed(l)), st),
+                    "mmst_encoder_layer_bwd_data")
+            weights_after_data()
+            L.check(lib.mmst_encoder_layer_bwd_weights(pl.n_groups, pl.modal_g[l], pl.modal_a[l], pl.modal_w[l],
+                                                       C.c_float(p_drop), wst), "mmst_encoder_layer_bwd_weights")
         # embeddings
         G_, s, keep = pl.embed_structs
-        wr = "B" if 0 % 2 == 0 else "A"
-        dx = (C.c_void_p * pl.n_groups)(*[_P(pl.modal_bwd[i]["dz" + wr]) for i in range(pl.n_groups)])
+        dx = (C.c_void_p * pl.n_groups)(*[_P(pl.dxseq[i]) for i in range(pl.n_groups)])
         L.check(lib.mmst_embed_bwd(pl.n_groups, G_, C.byref(s), dx, st), "mmst_embed_bwd")
         names = [n for n, _, _ in pl.mods]
         if "IR" in names:
@@ -654,3 +685,4 @@ class Engine:
                            ldp=D, ldq=1000, ldc=1000, Pn=D, Qn=1000, K=B, ksplit=1)], L.EPI_ATOMIC, pt=True, qt=True)
         if on_segment:
             on_segment("modal")
+        main.wait_stream(ws)   # everything after backward (optimizer, readers of .grad) sees all gradients

@@ -14,8 +14,8 @@ _PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", 
 
 def gemm_batch(groups):
     """groups: list of dicts with GemmProb field names; tensors for pointer fields."""
-    if not 1 <= len(groups) <= L.MAX_GROUPS:
-        raise L.MMSTError("gemm: 1..%d groups" % L.MAX_GROUPS)
+    if not 1 <= len(groups) <= L.GEMM_MAX_GROUPS:
+        raise L.MMSTError("gemm: 1..%d groups" % L.GEMM_MAX_GROUPS)
     b = L.GemmBatch()
     b.n = len(groups)
     for i, g in enumerate(groups):

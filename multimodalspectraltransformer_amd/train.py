@@ -37,13 +37,18 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
         self.works = []
 
-    def on_segment(self, name):
+    def on_segment(self, name, also=()):
+        """`also`: further streams whose already-enqueued work writes this segment (the weight-gradient
+        stream of the engine)."""
         if self.world == 1:
             return
         lo, hi = self.segments[name]
         view = self.flat[lo:hi]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
+            for s in also:
+                if s is not None:
+                    self.stream.wait_stream(s)
             with torch.cuda.stream(self.stream):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
@@ -154,7 +159,8 @@ class TransformerMultiGPU:
                     "modal": (0, ar.marks["cross"])}
             self.reducer = GradReducer(ar.G, segs, self.world)
         ar.G.zero_()
-        loss = model.loss_and_backward(x, on_segment=self.reducer.on_segment)
+        loss = model.loss_and_backward(
+            x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))
         scale = self.reducer.finish()
         self.optimizer.step(self.config.training_mode, grad_scale=scale)
         out = {'loss': loss}
