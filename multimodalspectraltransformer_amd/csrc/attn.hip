@@ -183,8 +183,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
   const bool dropping = batch.drop_p > 0.f;
-  const uint32_t Skp = (uint32_t)((Sk + 1) & ~1);
-  const uint32_t rowbase = (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)) * Skp;
+  const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)));
 
   bf16x8 qf[C::KS], dof[C::KS];
   load_owner<HD>(qf, pr.Q + (size_t)(b * Tq + (qvalid ? q : 0)) * pr.ldq + hh * HD, h, qvalid);
@@ -261,10 +260,10 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
 #pragma unroll
         for (int i = 0; i < C::OREGS; ++i) oacc[i] *= alpha;
         if (dropping) {
+          const uint32_t tbase = rseed + (uint32_t)((c0 + lk0) >> 1) * ATTN_PAIR_MUL + (uint32_t)(2 * h) * ATTN_PAIR_MUL;
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
-            uint32_t idx = rowbase + (uint32_t)(c0 + lk0 + acc_row(i, h));
-            uint32_t hb = drop_bits(pr.seed, idx >> 1);
+            uint32_t hb = attn_pair_bits(tbase, (uint32_t)(acc_row(i, 0) >> 1) * ATTN_PAIR_MUL);
             pv[i] = ((hb & 0xFFFFu) >= thr) ? pv[i] * dscale : 0.f;
             pv[i + 1] = ((hb >> 16) >= thr) ? pv[i + 1] * dscale : 0.f;
           }
@@ -274,13 +273,13 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
 #pragma unroll
         for (int s = 0; s < C::KS; ++s)
           dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Vimg, lk0 + r, s, h, hoff), dof[s], dpacc, 0, 0, 0);
+        const uint32_t tbase = rseed + (uint32_t)((c0 + lk0) >> 1) * ATTN_PAIR_MUL + (uint32_t)(2 * h) * ATTN_PAIR_MUL;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           float p0 = __builtin_amdgcn_exp2f(sv[i] - lse2), p1 = __builtin_amdgcn_exp2f(sv[i + 1] - lse2);
           float d0 = dpacc[i], d1 = dpacc[i + 1];
           if (dropping) {
-            uint32_t idx = rowbase + (uint32_t)(c0 + lk0 + acc_row(i, h));
-            uint32_t hb = drop_bits(pr.seed, idx >> 1);
+            uint32_t hb = attn_pair_bits(tbase, (uint32_t)(acc_row(i, 0) >> 1) * ATTN_PAIR_MUL);
             d0 = ((hb & 0xFFFFu) >= thr) ? d0 * dscale : 0.f;
             d1 = ((hb >> 16) >= thr) ? d1 * dscale : 0.f;
           }
@@ -310,13 +309,14 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
 template <int HD, bool CAUSAL>
 __global__ void attn_kv_kernel(const AttnBatch batch) {
   typedef Cfg<HD> C;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 2 * C::HG * KC * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 3 * C::HG * KC * 4];
   unsigned char* Qimg = smem;
   unsigned char* Dimg = smem + C::RM_BYTES;
   unsigned char* Qt = smem + 2 * C::RM_BYTES;
   unsigned char* Dt = Qt + C::TR_BYTES;
   float* lse_all = reinterpret_cast<float*>(Dt + C::TR_BYTES);   // [HG][KC]
   float* del_all = lse_all + C::HG * KC;
+  uint32_t* rs_all = reinterpret_cast<uint32_t*>(del_all + C::HG * KC);   // per-row dropout seeds
 
   const BlockCoord bc = locate<HD>(batch);
   const AttnProb& pr = batch.p[bc.g];
@@ -326,6 +326,7 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   const int b = bc.b, hh = bc.hg * C::HG + hl, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
   const float* lse_s = lse_all + hl * KC;
   const float* del_s = del_all + hl * KC;
+  const uint32_t* rs_s = rs_all + hl * KC;
   const int k0 = (bc.blk * C::TPB + wave / C::HG) * 32;
   const bool active = k0 < Sk;
   const int key = k0 + r;
@@ -335,7 +336,8 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
   const bool dropping = batch.drop_p > 0.f;
-  const uint32_t Skp = (uint32_t)((Sk + 1) & ~1);
+  const uint32_t pair_term = (uint32_t)(key >> 1) * ATTN_PAIR_MUL;
+  const uint32_t pair_shift = (key & 1) ? 16u : 0u;
 
   bf16x8 kf[C::KS], vf[C::KS];
   load_owner<HD>(kf, pr.K + (size_t)(b * Sk + (kvalid ? key : 0)) * pr.ldk + hh * HD, h, kvalid);
@@ -359,6 +361,7 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
       }
       lse_all[j] = lv;
       del_all[j] = dv;
+      if (dropping) rs_all[j] = attn_row_seed(pr.seed, (uint32_t)((b * H + bc.hg * C::HG + hj) * Tq + c0 + i));
     }
     __syncthreads();
     if (!active) continue;
@@ -377,6 +380,8 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
       for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 ll = *reinterpret_cast<const f32x4*>(lse_s + lq0 + 8 * g4 + 4 * h);
         f32x4 dd = *reinterpret_cast<const f32x4*>(del_s + lq0 + 8 * g4 + 4 * h);
+        const uint4 rr = *reinterpret_cast<const uint4*>(rs_s + lq0 + 8 * g4 + 4 * h);
+        const uint32_t rsv[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = 4 * g4 + j;
@@ -387,10 +392,8 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
           float d = dpacc[i];
           float pk = p;
           if (dropping) {
-            uint32_t idx = (uint32_t)((b * H + hh) * Tq + qg) * Skp + (uint32_t)key;
-            uint32_t hb = drop_bits(pr.seed, idx >> 1);
-            uint32_t bits = (key & 1) ? (hb >> 16) : (hb & 0xFFFFu);
-            bool keep = bits >= thr;
+            uint32_t hb = attn_pair_bits(rsv[j], pair_term);
+            bool keep = ((hb >> pair_shift) & 0xFFFFu) >= thr;
             d = keep ? d * dscale : 0.f;
             pk = keep ? p * dscale : 0.f;
           }

@@ -41,6 +41,21 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
   uint32_t b = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
   return b >= thr;
 }
+// Attention-probability dropout: the mask bit of (row, key) must be reproducible from two different
+// register layouts (query on the lane / key on the lane), so it is a function of a per-row seed (one full
+// mix per row) and the key PAIR (one cheap mix per pair, 16 bits per key).
+__device__ __forceinline__ uint32_t attn_row_seed(uint32_t seed, uint32_t rowid) {
+  return mix32(seed + rowid * 0x9E3779B9U);
+}
+__device__ __forceinline__ uint32_t attn_pair_bits(uint32_t row_seed, uint32_t pair_term) {
+  uint32_t t = row_seed + pair_term;   // pair_term = (key >> 1) * ATTN_PAIR_MUL
+  t ^= t >> 16;
+  t *= 0x7feb352dU;
+  t ^= t >> 15;
+  return t;
+}
+#define ATTN_PAIR_MUL 0x85EBCA6BU
+
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);
 }

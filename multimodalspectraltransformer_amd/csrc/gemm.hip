@@ -164,42 +164,64 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 
-  if (kbeg < kend) {
-    uint4 rp[4], rq[4];
-    g2r<PT>(rp, pr.P, pr.ldp, p0, pr.Pn, kbeg * BK, pr.K, tid);
-    g2r<QT>(rq, pr.Q, pr.ldq, q0, pr.Qn, kbeg * BK, pr.K, tid);
-    for (int kt = kbeg; kt < kend; ++kt) {
-      __syncthreads();
-      r2s<PT, false>(Pimg, rp, tid);
-      r2s<QT, true>(Qimg, rq, tid);
-      __syncthreads();
-      if (kt + 1 < kend) {
-        g2r<PT>(rp, pr.P, pr.ldp, p0, pr.Pn, (kt + 1) * BK, pr.K, tid);
-        g2r<QT>(rq, pr.Q, pr.ldq, q0, pr.Qn, (kt + 1) * BK, pr.K, tid);
+  // Main loop: register-staged tiles, TWO tiles in flight (named register sets A/B, statically indexed):
+  // the loads of tile k+2 are issued before tile k is computed, so each tile's global latency is covered
+  // by two compute phases even when the workgroup is alone on its CU (small grids, short K).
+  auto compute_tile = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf[MT], qf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (PT) pf[mt] = frag_t(Pimg, pw0 + mt * 16 + 4 * (lane & 3), ks, lane);
+        else pf[mt] = frag_n<false>(Pimg, pw0 + mt * 16 + (lane & 15), ks, lane);
       }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pf[MT], qf[NT];
+      for (int nt = 0; nt < NT; ++nt) {
+        if (QT) qf[nt] = frag_t(Qimg, qw0 + (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks, lane);
+        else qf[nt] = frag_n<true>(Qimg, qw0 + (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3), ks, lane);
+      }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (PT) pf[mt] = frag_t(Pimg, pw0 + mt * 16 + 4 * (lane & 3), ks, lane);
-          else pf[mt] = frag_n<false>(Pimg, pw0 + mt * 16 + (lane & 15), ks, lane);
-        }
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (QT) qf[nt] = frag_t(Qimg, qw0 + (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks, lane);
-          else qf[nt] = frag_n<true>(Qimg, qw0 + (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3), ks, lane);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], acc[mt][nt], 0, 0, 0);
+      if (EPI == EPI_ATOMIC && do_colsum) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], acc[mt][nt], 0, 0, 0);
-        if (EPI == EPI_ATOMIC && do_colsum) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[mt], bacc[mt], 0, 0, 0);
+          bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[mt], bacc[mt], 0, 0, 0);
+      }
+    }
+  };
+
+  if (kbeg < kend) {
+    uint4 rpA[4], rqA[4], rpB[4], rqB[4];
+    g2r<PT>(rpA, pr.P, pr.ldp, p0, pr.Pn, kbeg * BK, pr.K, tid);
+    g2r<QT>(rqA, pr.Q, pr.ldq, q0, pr.Qn, kbeg * BK, pr.K, tid);
+    if (kbeg + 1 < kend) {
+      g2r<PT>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kbeg + 1) * BK, pr.K, tid);
+      g2r<QT>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kbeg + 1) * BK, pr.K, tid);
+    }
+    for (int kt = kbeg; kt < kend; kt += 2) {
+      __syncthreads();
+      r2s<PT, false>(Pimg, rpA, tid);
+      r2s<QT, true>(Qimg, rqA, tid);
+      __syncthreads();
+      if (kt + 2 < kend) {
+        g2r<PT>(rpA, pr.P, pr.ldp, p0, pr.Pn, (kt + 2) * BK, pr.K, tid);
+        g2r<QT>(rqA, pr.Q, pr.ldq, q0, pr.Qn, (kt + 2) * BK, pr.K, tid);
+      }
+      compute_tile();
+      if (kt + 1 < kend) {
+        __syncthreads();
+        r2s<PT, false>(Pimg, rpB, tid);
+        r2s<QT, true>(Qimg, rqB, tid);
+        __syncthreads();
+        if (kt + 3 < kend) {
+          g2r<PT>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kt + 3) * BK, pr.K, tid);
+          g2r<QT>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kt + 3) * BK, pr.K, tid);
         }
+        compute_tile();
       }
     }
   }

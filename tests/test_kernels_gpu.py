@@ -58,6 +58,19 @@ def keep_mask(seed, idx, p):
     return bits >= thr
 
 
+def attn_keep_mask(seed, rowid, key, p):
+    """numpy restatement of attn_row_seed()/attn_pair_bits() in csrc/common.h"""
+    M = np.uint64(0xFFFFFFFF)
+    thr = int(p * 65536.0 + 0.5)
+    rs = mix32((np.uint64(seed) + rowid.astype(np.uint64) * np.uint64(0x9E3779B9)) & M)
+    t = (rs + (key.astype(np.uint64) >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & M
+    t ^= t >> np.uint64(16)
+    t = (t * np.uint64(0x7feb352d)) & M
+    t ^= t >> np.uint64(15)
+    bits = np.where((key.astype(np.uint64) & np.uint64(1)) == 1, t >> np.uint64(16), t & np.uint64(0xFFFF))
+    return bits >= thr
+
+
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (128, 128, 2048), (77, 64, 128), (1000, 2048, 128), (64, 128, 1024)])
 def test_gemm_bias_relu(M, N, K):
@@ -224,10 +237,10 @@ def run_attn(B, H, T, S, hd, causal, use_bias, p=0.0, seed=77, self_attn=True):
     vf = V.float()[:, vo:vo + d].reshape(B, S, H, hd).clone().requires_grad_(True)
     keep = None
     if p > 0:
-        Skp = (S + 1) & ~1
         b_, h_, t_, s_ = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(S), indexing="ij")
-        idx = ((b_ * H + h_) * T + t_) * Skp + s_
-        keep = torch.from_numpy(keep_mask(seed, idx.reshape(-1), p).reshape(B, H, T, S)).to(DEV)
+        rowid = (b_ * H + h_) * T + t_
+        keep = torch.from_numpy(attn_keep_mask(seed, rowid.reshape(-1), s_.reshape(-1), p).reshape(B, H, T, S)).to(DEV)
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.01
     ref = attn_ref(qf, kf, vf, bias, causal, hd, keep, p)
     close(O.reshape(B, T, H, hd), ref.detach())
     # backward
