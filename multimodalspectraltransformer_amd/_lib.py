@@ -54,6 +54,16 @@ class AttnBatch(C.Structure):
                 ("p", AttnProb * MAX_GROUPS)]
 
 
+class FfnProb(C.Structure):
+    _fields_ = [("epi", GemmProb), ("X", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("b1", C.c_void_p),
+                ("H", C.c_void_p), ("dH", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
+                ("tile_begin", C.c_int)]
+
+
+class FfnBatch(C.Structure):
+    _fields_ = [("n", C.c_int), ("p", FfnProb * MAX_GROUPS)]
+
+
 _lib = None
 
 
@@ -69,7 +79,8 @@ def lib():
             raise MMSTError(f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc, gfx950) first")
         _lib = C.CDLL(LIB_PATH)
         if _lib.mmst_sizeof_gemm_batch() != C.sizeof(GemmBatch) or \
-                _lib.mmst_sizeof_attn_batch() != C.sizeof(AttnBatch):
+                _lib.mmst_sizeof_attn_batch() != C.sizeof(AttnBatch) or \
+                _lib.mmst_sizeof_ffn_batch() != C.sizeof(FfnBatch):
             raise MMSTError("struct layout mismatch between _lib.py and libmmst.so")
     return _lib
 

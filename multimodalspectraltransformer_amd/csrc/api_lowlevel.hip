@@ -2,6 +2,7 @@
 // and for the one-off projections of the host layer (IR embedding, fingerprint head, vocabulary
 // projection and their gradients).  Structs are plain C (see gemm.h / attn.h).
 #include "attn.h"
+#include "ffn.h"
 #include "gemm.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,13 @@ int mmst_attn_bwd(const AttnBatch* batch, void* stream) {
   if (!batch) return MMST_ERR_ARG;
   AttnBatch b = *batch;
   return launch_attn_bwd(b, (hipStream_t)stream);
+}
+
+// fused feed-forward block: backward == 0 -> y = LN(x + drop(FFN(x))), else the activation-gradient pass
+int mmst_ffn(const FfnBatch* batch, int backward, void* stream) {
+  if (!batch) return MMST_ERR_ARG;
+  FfnBatch b = *batch;
+  return backward ? launch_ffn_bwd(b, (hipStream_t)stream) : launch_ffn_fwd(b, (hipStream_t)stream);
 }
 
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
@@ -70,5 +78,6 @@ int mmst_tap_read(float* total_ms, int* count, double* flops, double* bytes, cha
 
 int mmst_sizeof_gemm_batch() { return (int)sizeof(GemmBatch); }
 int mmst_sizeof_attn_batch() { return (int)sizeof(AttnBatch); }
+int mmst_sizeof_ffn_batch() { return (int)sizeof(FfnBatch); }
 int mmst_version() { return 1; }
 }

@@ -1,0 +1,31 @@
+// Fused feed-forward block of a post-LN transformer layer (gfx950): the two chained GEMMs of
+//   forward   y  = LN(x + drop(relu-drop(x W1^T + b1) W2^T + b2))
+//   backward  dx = LNbwd(((dz W2) * mask(h)) W1 + r)
+// run in ONE kernel per 128-row tile.  The 2048-wide hidden activation never returns from HBM between the
+// two GEMMs: it is produced 128 columns at a time in MFMA accumulators, re-packed in registers as the
+// token-side operand of the second GEMM and (forward only) written out once for the backward pass.
+#pragma once
+#include "gemm.h"
+
+#define FFN_MAX_GROUPS 6
+
+struct FfnProb {
+  GemmProb epi;        // final row epilogue (EPI_LN forward / EPI_LNBWD backward); Pn = rows, Qn = 128
+  const bf16* X;       // [M][128] token-side input: layer input (forward) or gradient of the FFN output (backward)
+  const bf16* W1;      // [2048][128]
+  const bf16* W2;      // [128][2048]
+  const float* b1;     // [2048] (forward)
+  bf16* H;             // [M][2048] hidden activation after ReLU and dropout: written (forward), read (backward)
+  bf16* dH;            // optional [M][2048] output of the backward kernel (gradient at the hidden pre-activation)
+  float drop_p;        // dropout on the hidden activation
+  uint32_t seed;
+  int tile_begin;      // filled by the launcher
+};
+
+struct FfnBatch {
+  int n;
+  FfnProb p[FFN_MAX_GROUPS];
+};
+
+int launch_ffn_fwd(FfnBatch& b, hipStream_t stream);
+int launch_ffn_bwd(FfnBatch& b, hipStream_t stream);

@@ -14,108 +14,9 @@
 // LDS images (16 KiB each, XOR-swizzled, conflict-free for the reads below):
 //   row-major operand      [128 index][64 c]  read with ds_read_b128
 //   contraction-major      [64 c][128 index]  read with ds_read_b64_tr_b16
-#include "gemm.h"
+#include "gemm_tile.h"
 
 namespace {
-
-constexpr int BP = 128, BQ = 128, BK = 64;
-
-__device__ __forceinline__ int fsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-
-// ---- global -> registers (one 128x64 / 64x128 bf16 tile = 4 x 16 B per thread) ----
-template <bool T>
-__device__ __forceinline__ void g2r(uint4 (&r)[4], const bf16* __restrict__ base, int ld, int i0, int iN,
-                                    int c0, int cN, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
-    int gi, gc;
-    size_t off;
-    if (!T) {
-      gi = i0 + (c >> 3);
-      gc = c0 + (c & 7) * 8;
-      off = (size_t)gi * ld + gc;
-    } else {
-      gc = c0 + (c >> 4);
-      gi = i0 + (c & 15) * 8;
-      off = (size_t)gc * ld + gi;
-    }
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gi < iN && gc < cN) v = *reinterpret_cast<const uint4*>(base + off);
-    r[i] = v;
-  }
-}
-
-// ---- registers -> LDS image.  QSW selects the swizzle key of the row-major image:
-// the P side is read with natural rows (key row&7), the Q side with interleaved rows.
-template <bool T, bool QSW>
-__device__ __forceinline__ void r2s(unsigned char* img, const uint4 (&r)[4], int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
-    int off;
-    if (!T) {
-      int row = c >> 3, ch = c & 7;
-      int key = QSW ? fsw(row) : (row & 7);
-      off = row * 128 + ((ch ^ key) << 4);
-    } else {
-      int row = c >> 4, ch = c & 15;
-      off = row * 256 + (((((ch >> 1) ^ fsw(row)) << 1) | (ch & 1)) << 4);
-    }
-    *reinterpret_cast<uint4*>(img + off) = r[i];
-  }
-}
-
-template <bool QSW>
-__device__ __forceinline__ bf16x8 frag_n(const unsigned char* img, int row, int ks, int lane) {
-  int chunk = ks * 4 + (lane >> 4);
-  int key = QSW ? fsw(row) : (row & 7);
-  return *reinterpret_cast<const bf16x8*>(img + row * 128 + ((chunk ^ key) << 4));
-}
-
-__device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int col, int ks, int lane) {
-  int krow = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
-  int off = krow * 256 + (((col >> 4) ^ fsw(krow)) << 5) + (col & 15) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + off));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + off + 4 * 256));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-__device__ __forceinline__ void load8(float (&o)[8], const bf16* p) {
-  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
-}
-__device__ __forceinline__ void load8f(float (&o)[8], const float* p) {
-  f32x4 a = *reinterpret_cast<const f32x4*>(p);
-  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-}
-__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-  *reinterpret_cast<bf16x8*>(p) = o;
-}
-__device__ __forceinline__ void store8f(float* p, const float (&v)[8]) {
-  f32x4 a, b;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
-  *reinterpret_cast<f32x4*>(p) = a;
-  *reinterpret_cast<f32x4*>(p + 4) = b;
-}
-// dropout over 8 consecutive element indices starting at idx (idx % 8 == 0)
-__device__ __forceinline__ void drop8(float (&v)[8], uint32_t seed, uint32_t idx, uint32_t thr, float scale) {
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    uint32_t h = drop_bits(seed, (idx + e) >> 1);
-    v[e] = ((h & 0xFFFFu) >= thr) ? v[e] * scale : 0.f;
-    v[e + 1] = ((h >> 16) >= thr) ? v[e + 1] * scale : 0.f;
-  }
-}
 
 template <int EPI, bool PT, bool QT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
@@ -314,166 +215,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   }
 
   if constexpr (EPI == EPI_LN) {
-    float gam[4][8], bet[4][8];
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-      load8f(gam[tp], pr.gamma + tp * 32 + 8 * q);
-      load8f(bet[tp], pr.beta + tp * 32 + 8 * q);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = p0 + pw0 + mt * 16 + (lane & 15);
-      const bool ok = m < pr.Pn;
-      float z[4][8];
-      float s = 0.f;
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp) {
-        const int n = tp * 32 + 8 * q;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { z[tp][e] = acc[mt][2 * tp][e]; z[tp][4 + e] = acc[mt][2 * tp + 1][e]; }
-        if (pr.bias) {
-          float b[8];
-          load8f(b, pr.bias + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[tp][e] += b[e];
-        }
-        if (pr.drop_p > 0.f) drop8(z[tp], pr.seed, (uint32_t)m * 128u + n, thr, dscale);
-        if (ok && pr.R) {
-          float r[8];
-          load8(r, pr.R + rrow(m) * pr.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[tp][e] += r[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += z[tp][e];
-      }
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      const float mean = s * (1.0f / 128.0f);
-      float vs = 0.f;
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { float d = z[tp][e] - mean; vs += d * d; }
-      vs += __shfl_xor(vs, 16);
-      vs += __shfl_xor(vs, 32);
-      const float rstd = rsqrtf(vs * (1.0f / 128.0f) + 1e-5f);
-      if (ok) {
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-          const int n = tp * 32 + 8 * q;
-          if (pr.Z) store8(pr.Z + (size_t)m * 128 + n, z[tp]);
-          float y[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = (z[tp][e] - mean) * rstd * gam[tp][e] + bet[tp][e];
-          store8((bf16*)pr.C + crow(m) * pr.ldc + n, y);
-        }
-        if (q == 0 && pr.stats) { pr.stats[2 * (size_t)m] = mean; pr.stats[2 * (size_t)m + 1] = rstd; }
-      }
-    }
+    if constexpr (ROWEPI) epi_ln(acc, pr, p0, pw0, lane);
   }
 
   if constexpr (EPI == EPI_LNBWD) {
-    float gam[4][8];
-    float pg[4][8], pb[4][8];
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-      load8f(gam[tp], pr.gamma + tp * 32 + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { pg[tp][e] = 0.f; pb[tp][e] = 0.f; }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = p0 + pw0 + mt * 16 + (lane & 15);
-      const bool ok = m < pr.Pn;
-      float mean = 0.f, rstd = 0.f;
-      if (ok) { mean = pr.stats[2 * (size_t)m]; rstd = pr.stats[2 * (size_t)m + 1]; }
-      float gy[4][8], xh[4][8];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp) {
-        const int n = tp * 32 + 8 * q;
-        float dy[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { dy[e] = acc[mt][2 * tp][e]; dy[4 + e] = acc[mt][2 * tp + 1][e]; }
-        float zz[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) zz[e] = 0.f;
-        if (ok) {
-          if (pr.R) {
-            float r[8];
-            load8(r, pr.R + rrow(m) * pr.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dy[e] += r[e];
-          }
-          load8(zz, pr.Z + (size_t)m * 128 + n);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dy[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = ok ? (zz[e] - mean) * rstd : 0.f;
-          xh[tp][e] = x;
-          gy[tp][e] = dy[e] * gam[tp][e];
-          s1 += gy[tp][e];
-          s2 += gy[tp][e] * x;
-          pg[tp][e] += dy[e] * x;
-          pb[tp][e] += dy[e];
-        }
-      }
-      s1 += __shfl_xor(s1, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
-      s1 *= (1.0f / 128.0f);
-      s2 *= (1.0f / 128.0f);
-      if (ok) {
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-          const int n = tp * 32 + 8 * q;
-          float dz[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dz[e] = rstd * (gy[tp][e] - s1 - xh[tp][e] * s2);
-          store8((bf16*)pr.C + (size_t)m * pr.ldc + n, dz);
-          if (pr.C2) {
-            if (pr.drop_p > 0.f) drop8(dz, pr.seed, (uint32_t)m * 128u + n, thr, dscale);
-            store8(pr.C2 + (size_t)m * 128 + n, dz);
-          }
-        }
-      }
-    }
-    // column sums over the tile's 128 rows: 16 lanes (lane&15) in-wave, then 4 waves via LDS
-    if (pr.dgamma) {
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float a = pg[tp][e], b = pb[tp][e];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-          pg[tp][e] = a;
-          pb[tp][e] = b;
-        }
-      __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][128]
-      if ((lane & 15) == 0) {
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            red[(wave * 2 + 0) * 128 + tp * 32 + 8 * q + e] = pg[tp][e];
-            red[(wave * 2 + 1) * 128 + tp * 32 + 8 * q + e] = pb[tp][e];
-          }
-      }
-      __syncthreads();
-      {
-        int which = tid >> 7, col = tid & 127;
-        float s = red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col] +
-                  red[(2 * 2 + which) * 128 + col] + red[(3 * 2 + which) * 128 + col];
-        atomicAdd((which ? pr.dbeta : pr.dgamma) + col, s);
-      }
-    }
+    if constexpr (ROWEPI) epi_lnbwd(acc, pr, p0, pw0, lane, wave, tid, smem);
   }
 }
 

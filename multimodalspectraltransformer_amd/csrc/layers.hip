@@ -2,6 +2,7 @@
 // attention launches (see gemm.h / attn.h).  Nothing is allocated and no state is kept here.
 #include "../../include/mmst.h"
 #include "attn.h"
+#include "ffn.h"
 #include "gemm.h"
 #include <stdlib.h>
 #include <string.h>
@@ -94,6 +95,37 @@ inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st) {
   return MMST_OK;
 }
 
+// feed-forward block forward: y = LN(x + drop(linear2(drop(relu(linear1(x))))))
+inline FfnProb ffn_fwd_prob(const void* x, int M, const void* w1, const float* b1, const void* w2, const float* b2,
+                            const float* gamma, const float* beta, void* h, void* z, float* stats, void* y,
+                            float drop_p, uint32_t seed_hidden, uint32_t seed_out) {
+  FfnProb f;
+  memset(&f, 0, sizeof(f));
+  GemmProb g = zero_prob();
+  g.Pn = M; g.Qn = D; g.K = FF;
+  g.C = y; g.ldc = D; g.bias = b2;
+  g.R = (const bf16*)x; g.ldr = D;
+  g.gamma = gamma; g.beta = beta; g.Z = (bf16*)z; g.stats = stats;
+  g.drop_p = drop_p; g.seed = seed_out;
+  f.epi = g;
+  f.X = (const bf16*)x; f.W1 = (const bf16*)w1; f.W2 = (const bf16*)w2; f.b1 = b1;
+  f.H = (bf16*)h; f.drop_p = drop_p; f.seed = seed_hidden;
+  return f;
+}
+// feed-forward block backward (activations): dx_in = LNbwd_prev(((dzd W2) * mask(h)) W1 + dz)
+inline FfnProb ffn_bwd_prob(const void* dzd, const void* dz, int M, const void* w1, const void* w2, const void* h,
+                            void* dh, float drop_p) {
+  FfnProb f;
+  memset(&f, 0, sizeof(f));
+  GemmProb g = zero_prob();
+  g.Pn = M; g.Qn = D; g.K = FF;
+  g.R = (const bf16*)dz; g.ldr = D;
+  f.epi = g;
+  f.X = (const bf16*)dzd; f.W1 = (const bf16*)w1; f.W2 = (const bf16*)w2;
+  f.H = (bf16*)h; f.dH = (bf16*)dh; f.drop_p = drop_p;
+  return f;
+}
+
 #define RUN(expr)            \
   do {                       \
     int rc__ = (expr);       \
@@ -139,23 +171,16 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
     gb.p[i] = g;
   }
   RUN(launch_gemm(gb, EPI_LN, false, false, st));
-  // 4. linear1 + relu + dropout
+  // 4. feed-forward block + norm2, one kernel
+  FfnBatch fb;
+  fb.n = n;
   for (int i = 0; i < n; ++i) {
-    GemmProb g = fwd_linear(a[i].x1, a[i].B * a[i].S, D, p[i].w_1, FF, p[i].b_1, a[i].h);
-    g.flags = GF_RELU; g.drop_p = drop_p; g.seed = seed + 8 * i + 2;
-    gb.p[i] = g;
+    FfnProb f = ffn_fwd_prob(a[i].x1, a[i].B * a[i].S, p[i].w_1, p[i].b_1, p[i].w_2, p[i].b_2, p[i].g2, p[i].be2, a[i].h,
+                             a[i].z2, a[i].st2, a[i].y, drop_p, seed + 8 * i + 2, seed + 8 * i + 3);
+    if (a[i].y_L > 0) { f.epi.cS = a[i].S; f.epi.cL = a[i].y_L; f.epi.coff = a[i].y_off; }
+    fb.p[i] = f;
   }
-  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
-  // 5. linear2 + dropout + residual + norm2
-  for (int i = 0; i < n; ++i) {
-    GemmProb g = fwd_linear(a[i].h, a[i].B * a[i].S, FF, p[i].w_2, D, p[i].b_2, a[i].y);
-    g.R = (const bf16*)a[i].x1; g.ldr = D;
-    g.gamma = p[i].g2; g.beta = p[i].be2; g.Z = (bf16*)a[i].z2; g.stats = a[i].st2;
-    g.drop_p = drop_p; g.seed = seed + 8 * i + 3;
-    if (a[i].y_L > 0) { g.cS = a[i].S; g.cL = a[i].y_L; g.coff = a[i].y_off; }
-    gb.p[i] = g;
-  }
-  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  RUN(launch_ffn_fwd(fb, st));
   return MMST_OK;
 }
 
@@ -167,24 +192,20 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
   const int hd = D / nhead;
   GemmBatch gb;
   gb.n = n;
-  // dh = (dzd2 W2) * relu'/dropout mask
+  // feed-forward block backward fused with norm1 backward: dz1 = LNbwd(((dzd2 W2) * mask(h)) W1 + dz2)
+  FfnBatch fb;
+  fb.n = n;
   for (int i = 0; i < n; ++i) {
-    GemmProb q = dgrad(w[i].dzd2, a[i].B * a[i].S, D, p[i].w_2, FF, w[i].dh);
-    q.R = (const bf16*)a[i].h; q.ldr = FF; q.drop_p = drop_p;
-    gb.p[i] = q;
-  }
-  RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
-  // dx1 = dh W1 + dz2 -> norm1 backward
-  for (int i = 0; i < n; ++i) {
-    GemmProb q = dgrad(w[i].dh, a[i].B * a[i].S, FF, p[i].w_1, D, w[i].dz1);
-    q.R = (const bf16*)w[i].dz2; q.ldr = D;
+    FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1, p[i].w_2, a[i].h, w[i].dh, drop_p);
+    GemmProb& q = f.epi;
+    q.C = w[i].dz1; q.ldc = D;
     q.Z = (bf16*)a[i].z1; q.stats = a[i].st1; q.gamma = p[i].g1;
     q.C2 = drop_p > 0.f ? (bf16*)w[i].dzd1 : nullptr;
     q.dgamma = g[i].g1; q.dbeta = g[i].be1;
     q.drop_p = drop_p; q.seed = seed + 8 * i + 1;
-    gb.p[i] = q;
+    fb.p[i] = f;
   }
-  RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
+  RUN(launch_ffn_bwd(fb, st));
   // da = dzd1 Wo
   for (int i = 0; i < n; ++i) {
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
@@ -323,20 +344,14 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
     gb.p[0] = g;
   }
   RUN(launch_gemm(gb, EPI_LN, false, false, st));
-  // feed-forward block
+  // feed-forward block + norm3, one kernel
   {
-    GemmProb g = fwd_linear(a->x2, M, D, p->w_1, FF, p->b_1, a->h);
-    g.flags = GF_RELU; g.drop_p = drop_p; g.seed = seed + 4;
-    gb.p[0] = g;
+    FfnBatch fb;
+    fb.n = 1;
+    fb.p[0] = ffn_fwd_prob(a->x2, M, p->w_1, p->b_1, p->w_2, p->b_2, p->g3, p->be3, a->h, a->z3, a->st3, a->y, drop_p,
+                           seed + 4, seed + 5);
+    RUN(launch_ffn_fwd(fb, st));
   }
-  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
-  {
-    GemmProb g = fwd_linear(a->h, M, FF, p->w_2, D, p->b_2, a->y);
-    g.R = (const bf16*)a->x2; g.ldr = D; g.gamma = p->g3; g.beta = p->be3; g.Z = (bf16*)a->z3; g.stats = a->st3;
-    g.drop_p = drop_p; g.seed = seed + 5;
-    gb.p[0] = g;
-  }
-  RUN(launch_gemm(gb, EPI_LN, false, false, st));
   return MMST_OK;
 }
 
@@ -349,21 +364,18 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
   const bool dr = drop_p > 0.f;
   GemmBatch gb;
   gb.n = 1;
-  // feed-forward block
+  // feed-forward block backward fused with norm2 backward
   {
-    GemmProb q = dgrad(w->dzd3, M, D, p->w_2, FF, w->dh);
-    q.R = (const bf16*)a->h; q.ldr = FF; q.drop_p = drop_p;
-    gb.p[0] = q;
-  }
-  RUN(launch_gemm(gb, EPI_DRELU, false, true, st));
-  {
-    GemmProb q = dgrad(w->dh, M, FF, p->w_1, D, w->dz2);
-    q.R = (const bf16*)w->dz3; q.ldr = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
+    FfnBatch fb;
+    fb.n = 1;
+    FfnProb f = ffn_bwd_prob(w->dzd3, w->dz3, M, p->w_1, p->w_2, a->h, w->dh, drop_p);
+    GemmProb& q = f.epi;
+    q.C = w->dz2; q.ldc = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
     q.C2 = dr ? (bf16*)w->dzd2 : nullptr; q.dgamma = g->g2; q.dbeta = g->be2;
     q.drop_p = drop_p; q.seed = seed + 3;
-    gb.p[0] = q;
+    fb.p[0] = f;
+    RUN(launch_ffn_bwd(fb, st));
   }
-  RUN(launch_gemm(gb, EPI_LNBWD, false, true, st));
   const void* dzd2 = dr ? w->dzd2 : w->dz2;
   // cross-attention block
   gb.p[0] = dgrad(dzd2, M, D, p->w_co, D, w->da2);

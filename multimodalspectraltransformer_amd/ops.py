@@ -65,6 +65,32 @@ def attn_bwd_launch(batch):
     L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
 
 
+_FPTR = ("X", "W1", "W2", "b1", "H", "dH")
+
+
+def ffn_batch(groups):
+    """groups: list of dicts; key "epi" holds a dict of GemmProb fields for the final row epilogue."""
+    if not 1 <= len(groups) <= L.MAX_GROUPS:
+        raise L.MMSTError("ffn: 1..%d groups" % L.MAX_GROUPS)
+    b = L.FfnBatch()
+    b.n = len(groups)
+    for i, g in enumerate(groups):
+        p = b.p[i]
+        for k, v in g.items():
+            if k == "epi":
+                for ek, ev in v.items():
+                    setattr(p.epi, ek, (L.ptr(ev) if isinstance(ev, torch.Tensor) else ev) if ek in _PTR_FIELDS else ev)
+            elif k in _FPTR:
+                setattr(p, k, L.ptr(v) if isinstance(v, torch.Tensor) else v)
+            else:
+                setattr(p, k, v)
+    return b
+
+
+def ffn_launch(batch, backward=False):
+    L.check(L.lib().mmst_ffn(C.byref(batch), int(backward), L.stream_ptr()), "mmst_ffn")
+
+
 def eptr(t, offset_elems):
     """Device address of element `offset_elems` of tensor t."""
     return t.data_ptr() + offset_elems * t.element_size()

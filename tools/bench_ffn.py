@@ -1,0 +1,31 @@
+"""Micro-benchmark of the fused feed-forward kernels.  usage: bench_ffn.py [lib.so] [M ...]"""
+import sys, os, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import multimodalspectraltransformer_amd._lib as L
+args = sys.argv[1:]
+if args and args[0].endswith(".so"):
+    L.LIB_PATH = os.path.abspath(args.pop(0))
+from multimodalspectraltransformer_amd import ops
+Ms = [int(a) for a in args] or [37248, 4032]
+dev = "cuda"
+for M in Ms:
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    x = r(M, 128).bfloat16(); w1 = (r(2048, 128) * 0.05).bfloat16(); w2 = (r(128, 2048) * 0.05).bfloat16()
+    b1 = r(2048) * 0.1; b2 = r(128) * 0.1; gam = torch.ones(128, device=dev); bet = torch.zeros(128, device=dev)
+    h = torch.empty(M, 2048, device=dev, dtype=torch.bfloat16); z = torch.empty(M, 128, device=dev, dtype=torch.bfloat16)
+    y = torch.empty_like(z); st = torch.empty(M, 2, device=dev)
+    fb = ops.ffn_batch([dict(X=x, W1=w1, W2=w2, b1=b1, H=h, drop_p=0.1, seed=7,
+                             epi=dict(Pn=M, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st, drop_p=0.1, seed=9))])
+    dzd = r(M, 128).bfloat16(); dz = r(M, 128).bfloat16(); dz1 = torch.empty_like(z); dzd1 = torch.empty_like(z)
+    dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev)
+    bb = ops.ffn_batch([dict(X=dzd, W1=w1, W2=w2, H=h, drop_p=0.1,
+                             epi=dict(Pn=M, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, C2=dzd1, dgamma=dg, dbeta=db, drop_p=0.1, seed=5))])
+    for name, b, bwd in (("fwd", fb, False), ("bwd", bb, True)):
+        for _ in range(3): ops.ffn_launch(b, bwd)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): ops.ffn_launch(b, bwd)
+        e1.record(); torch.cuda.synchronize()
+        print("M=%d %s %.1f us" % (M, name, e0.elapsed_time(e1) * 1000 / 20), flush=True)
