@@ -71,6 +71,25 @@ __device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int col, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// The same transposing read issued as inline assembly, for loops that keep LDS-DMA (global_load_lds) in flight:
+// the compiler orders every LDS read it can see behind a pending LDS-DMA with s_waitcnt vmcnt(0), which would
+// drain the DMA pipeline each step.  The caller waits with lds_wait*() before using lo/hi.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void frag_t_issue(s16x4& lo, s16x4& hi, const unsigned char* img, int col, int ks, int lane) {
+  int krow = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+  int off = krow * 256 + (((col >> 4) ^ fsw(krow)) << 5) + (col & 15) * 2;
+  uint32_t a = (uint32_t)(uintptr_t)(LDS_AS const unsigned char*)(img + off);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a));
+}
+__device__ __forceinline__ void lds_wait4(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+__device__ __forceinline__ bf16x8 frag_join(s16x4 lo, s16x4 hi) {
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 __device__ __forceinline__ void load8(float (&o)[8], const bf16* p) {
   bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
