@@ -37,6 +37,8 @@ typedef struct {
   const void* w_2;   const float* b_2;     /* linear2 [128][2048] */
   const float* g1; const float* be1;       /* norm1 */
   const float* g2; const float* be2;       /* norm2 */
+  const void* w_1t;  const void* w_2t;     /* bf16 transposes linear1^T [128][2048], linear2^T [2048][128]:
+                                              read by the backward pass only (mmst_transpose_bf16 makes them) */
 } mmst_enc_params;
 
 typedef struct {  /* fp32 gradient buffers, same shapes as the parameters */
@@ -93,6 +95,7 @@ typedef struct {
   const void* w_cqkv; const float* b_cqkv; const void* w_co; const float* b_co;  /* multihead_attn */
   const void* w_1; const float* b_1; const void* w_2; const float* b_2;
   const float* g1; const float* be1; const float* g2; const float* be2; const float* g3; const float* be3;
+  const void* w_1t; const void* w_2t;   /* bf16 transposes of linear1 / linear2, backward pass only */
 } mmst_dec_params;
 
 typedef struct {
@@ -197,6 +200,11 @@ int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_
                float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* fp32 -> bf16 copy of a [rows][cols] matrix into a [rows][ld_out] one (padded weight copies). */
 int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, void* stream);
+
+/* bf16 transposes of n equally shaped [rows][cols] matrices: matrix i is read at src + offsets[i] and written as
+ * [cols][rows] at dst + offsets[i] (element offsets, host array, n <= 128).  Keeps the transposed feed-forward
+ * weights the backward pass reads in step with the bf16 weight copy after an optimizer step. */
+int mmst_transpose_bf16(const void* src, void* dst, int n, const uint32_t* offsets, int rows, int cols, void* stream);
 
 int mmst_version(void);
 

@@ -107,7 +107,8 @@ def _ptrs(*names):
 
 
 class EncParams(C.Structure):
-    _fields_ = _ptrs("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "g1", "be1", "g2", "be2")
+    _fields_ = _ptrs("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "g1", "be1", "g2", "be2",
+                     "w_1t", "w_2t")
 
 
 class EncGrads(C.Structure):
@@ -129,7 +130,7 @@ _DEC_P = ("w_qkv", "b_qkv", "w_o", "b_o", "w_cqkv", "b_cqkv", "w_co", "b_co", "w
 
 
 class DecParams(C.Structure):
-    _fields_ = _ptrs(*_DEC_P)
+    _fields_ = _ptrs(*(_DEC_P + ("w_1t", "w_2t")))
 
 
 class DecGrads(C.Structure):

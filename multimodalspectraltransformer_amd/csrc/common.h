@@ -41,9 +41,10 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
   uint32_t b = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
   return b >= thr;
 }
-// Attention-probability dropout: the mask bit of (row, key) must be reproducible from two different
-// register layouts (query on the lane / key on the lane), so it is a function of a per-row seed (one full
-// mix per row) and the key PAIR (one cheap mix per pair, 16 bits per key).
+// Row-seeded dropout (attention probabilities; hidden activation of the fused feed-forward block): the mask
+// bit of (row, column) is a function of a per-row seed (one full mix per row) and the column PAIR (one cheap
+// mix per pair, 16 bits per column), so it costs one integer multiply per two elements and can be regenerated
+// from any register layout.
 __device__ __forceinline__ uint32_t attn_row_seed(uint32_t seed, uint32_t rowid) {
   return mix32(seed + rowid * 0x9E3779B9U);
 }

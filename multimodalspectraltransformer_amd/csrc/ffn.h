@@ -12,8 +12,8 @@
 struct FfnProb {
   GemmProb epi;        // final row epilogue (EPI_LN forward / EPI_LNBWD backward); Pn = rows, Qn = 128
   const bf16* X;       // [M][128] token-side input: layer input (forward) or gradient of the FFN output (backward)
-  const bf16* W1;      // [2048][128]
-  const bf16* W2;      // [128][2048]
+  const bf16* W1;      // first-GEMM weight  [2048][128]: linear1 (forward), transpose of linear2 (backward)
+  const bf16* W2;      // second-GEMM weight [128][2048]: linear2 (forward), transpose of linear1 (backward)
   const float* b1;     // [2048] (forward)
   bf16* H;             // [M][2048] hidden activation after ReLU and dropout: written (forward), read (backward)
   bf16* dH;            // optional [M][2048] output of the backward kernel (gradient at the hidden pre-activation)

@@ -27,39 +27,41 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base + 16 * lane)
 __device__ __forceinline__ void glds16(const bf16* src, unsigned char* dst) {
+#ifndef FFN_NO_DMA
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+#endif
 }
 
-enum ImgKind { IMG_W1_FWD, IMG_W2_FWD, IMG_W2_BWD, IMG_H_BWD, IMG_W1_BWD };
+enum ImgKind { IMG_W1_FWD, IMG_W2_FWD, IMG_H_BWD };
 
 // Per-lane element offset (relative to chunk 0) of the 16 bytes lane `lane` of wave `wave` contributes to DMA
 // instruction j (0..3) of an image.  Row-major images: 8 rows of 128 B per instruction; contraction-major
 // images: 4 rows of 256 B per instruction.
 template <int KIND>
 __device__ __forceinline__ uint32_t src_offset(int wave, int lane, int j, int p0, int M) {
-  if (KIND == IMG_W1_FWD || KIND == IMG_W2_FWD || KIND == IMG_H_BWD) {
+  {
     const int r = wave * 32 + j * 8 + (lane >> 3), s = lane & 7;
     if (KIND == IMG_W1_FWD) return (uint32_t)((r & 63) * DM + (r >> 6) * 64 + ((s ^ fsw(r)) << 3));
     if (KIND == IMG_W2_FWD) return (uint32_t)(r * FF + ((s ^ fsw(r)) << 3));
     const int m = (p0 + r < M) ? p0 + r : M - 1;
     return (uint32_t)m * FF + (uint32_t)((s ^ (r & 7)) << 3);   // M * FF < 2^32 is checked by the launcher
-  } else {
-    const int r = wave * 16 + j * 4 + (lane >> 4), s = lane & 15;
-    const int ch = (((s >> 1) ^ fsw(r)) << 1) | (s & 1);
-    if (KIND == IMG_W2_BWD) return (uint32_t)((((ch * 8) >> 6) * 64 + r) * FF + ((ch * 8) & 63));
-    return (uint32_t)(r * DM + ch * 8);
   }
 }
 // element stride of one hidden chunk for each image kind
 template <int KIND> __device__ __forceinline__ constexpr uint32_t chunk_stride() {
-  return (KIND == IMG_W1_FWD || KIND == IMG_W1_BWD) ? (uint32_t)HC * DM : (uint32_t)HC;
+  return KIND == IMG_W1_FWD ? (uint32_t)HC * DM : (uint32_t)HC;
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
-  // one array: DMA ring (4 x 16 KiB), then the first-layer bias (forward) / column-sum scratch (backward)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT + FF * 4];
-  float* b1s = reinterpret_cast<float*>(smem + NSLOT * SLOT);
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- backward (activation gradients) ----------------------------------------------------------------------
+// Same chained-GEMM structure with the transposed weight copies, so both GEMMs read row-major images:
+//   g  = dz W2        first GEMM, weight image from W2^T [2048][128]
+//   dh = g * mask(h)  mask = saved hidden activation > 0 (ReLU and dropout at once), h tile by LDS-DMA
+//   dx += dh W1       second GEMM, weight image from W1^T [128][2048]
+// Three images per chunk through a ring of four slots, three images ahead, one barrier per image.
+__global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0;
@@ -72,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
   const int pw0 = wave * 32;
   const int q = lane >> 4;
 
-  // token-side fragments of the first GEMM, resident for the whole kernel
   bf16x8 xf[2][4];
+  uint32_t hoff[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
@@ -83,12 +85,11 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
       if (m < M) v = *reinterpret_cast<const uint4*>(pr.X + (size_t)m * DM + ks * 32 + 8 * q);
       xf[mt][ks] = __builtin_bit_cast(bf16x8, v);
     }
+    hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;
   }
-  if (!BWD) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<f32x4*>(b1s + (tid + 256 * i) * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + (tid + 256 * i) * 4);
-  }
+  // optional copy of dh for a separate weight-gradient pass; zero records = every store dropped
+  const auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(pr.dH ? pr.dH : pr.H), 0,
+                                                       pr.dH ? (int)((uint32_t)M * FF * 2) : 0, 0x00020000);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -98,56 +99,41 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int NIMG = BWD ? 3 : 2, TOTAL = NCHUNK * NIMG;
-  // per-lane source offsets of the 4 DMA instructions of each image kind (loop invariant)
+  constexpr int NIMG = 3, TOTAL = NCHUNK * NIMG;
   uint32_t offA[4], offB[4], offH[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    offA[j] = BWD ? src_offset<IMG_W2_BWD>(wave, lane, j, p0, M) : src_offset<IMG_W1_FWD>(wave, lane, j, p0, M);
-    offB[j] = BWD ? src_offset<IMG_W1_BWD>(wave, lane, j, p0, M) : src_offset<IMG_W2_FWD>(wave, lane, j, p0, M);
-    offH[j] = BWD ? src_offset<IMG_H_BWD>(wave, lane, j, p0, M) : 0u;
+    offA[j] = src_offset<IMG_W1_FWD>(wave, lane, j, p0, M);
+    offB[j] = src_offset<IMG_W2_FWD>(wave, lane, j, p0, M);
+    offH[j] = src_offset<IMG_H_BWD>(wave, lane, j, p0, M);
   }
-  // image i of the sequence = phase (i % NIMG) of chunk (i / NIMG), into ring slot (i % 4)
+  // image i of the sequence = phase (i % 3) of chunk (i / 3), into ring slot (i % 4)
   auto issue = [&](int c, int ph, int i) {
     unsigned char* dst = smem + (i & (NSLOT - 1)) * SLOT + wave * (SLOT / 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bf16* src;
-      if (!BWD) {
-        src = ph == 0 ? pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
-                      : pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
-      } else {
-        src = ph == 0 ? pr.W2 + offA[j] + (uint32_t)c * chunk_stride<IMG_W2_BWD>()
-            : ph == 1 ? pr.H + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>()
-                      : pr.W1 + offB[j] + (uint32_t)c * chunk_stride<IMG_W1_BWD>();
-      }
+      const bf16* src = ph == 0 ? pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
+                      : ph == 1 ? pr.H + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>()
+                                : pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
       glds16(src, dst + j * 1024);
     }
   };
-  // own DMA portions of image i have landed once at most the (up to two) younger images are outstanding;
-  // the hidden-activation stores issued in between only make the count conservative
+  // Own DMA portions of image i have landed once only what was issued after them is outstanding: the two younger
+  // images (8 DMA instructions) and the 4 dh stores of the one mask step among the last three steps.
   auto wait_image = [&](int i) {
-    if (i + 2 < TOTAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (i + 2 < TOTAL) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (i + 1 < TOTAL) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  // weight-side fragment of output-column tile nt; `half` selects the packed half of a first-GEMM image
-  // (backward: contraction-major images, transposing reads issued by hand, see frag_t_issue)
-  auto qfrag = [&](const unsigned char* img, int nt, int half, int ks) -> bf16x8 {
-    return frag_n<true>(img, half * 64 + (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3), ks, lane);
-  };
-
+  auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
-  const uint32_t thr = drop_threshold(pr.drop_p);
 
   issue(0, 0, 0);
   issue(0, 1, 1);
-  if (BWD) issue(0, 2, 2);
-  else issue(1, 0, 2);
+  issue(0, 2, 2);
 
   for (int c = 0; c < NCHUNK; ++c) {
     int i = c * NIMG;
-    // ---- first GEMM: a1[32 rows][64 hidden] over the 128 model columns
     f32x4 a1[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -156,23 +142,13 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
     {
       wait_image(i);
       __builtin_amdgcn_s_barrier();
-      if (i + AHEAD < TOTAL) { if (BWD) issue(c + 1, 0, i + AHEAD); else issue(c + 1, 1, i + AHEAD); }
+      if (i + AHEAD < TOTAL) issue(c + 1, 0, i + AHEAD);
       const unsigned char* img = smem + (i & (NSLOT - 1)) * SLOT;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 qf[4];
-        if (BWD) {
-          s16x4 lo[4], hi[4];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            frag_t_issue(lo[nt], hi[nt], img, (ks >> 1) * 64 + (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks & 1, lane);
-          lds_wait4(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) qf[nt] = frag_join(lo[nt], hi[nt]);
-        } else {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) qf[nt] = qfrag(img, nt, ks >> 1, ks & 1);
-        }
+        for (int nt = 0; nt < 4; ++nt) qf[nt] = frag_n<true>(img, (ks >> 1) * 64 + qrow(nt), ks & 1, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -181,68 +157,39 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
       }
       ++i;
     }
-    // ---- hidden chunk: epilogue of the first GEMM, re-packed as the token-side operand of the second
-    const unsigned char* himg = nullptr;
-    if (BWD) {
-      wait_image(i);
-      __builtin_amdgcn_s_barrier();
-      if (i + AHEAD < TOTAL) issue(c + 1, 1, i + AHEAD);
-      himg = smem + (i & (NSLOT - 1)) * SLOT;
-      ++i;
-    }
     bf16x8 hf[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = p0 + pw0 + mt * 16 + (lane & 15);
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
-        const int n = c * HC + tp * 32 + 8 * q;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = a1[mt][2 * tp][e]; v[4 + e] = a1[mt][2 * tp + 1][e]; }
-        if (!BWD) {
-          float b[8];
-          load8f(b, b1s + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + b[e], 0.f);
-          if (pr.drop_p > 0.f) drop8(v, pr.seed, (uint32_t)m * (uint32_t)FF + n, thr, dscale);
-        } else {
-          bf16x8 h = frag_n<false>(himg, pw0 + mt * 16 + (lane & 15), tp, lane);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (float)h[e] > 0.f ? v[e] * dscale : 0.f;
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        hf[mt][tp] = o;
-        if (m < M) {
-          if (!BWD) *reinterpret_cast<bf16x8*>(pr.H + (size_t)m * FF + n) = o;
-          else if (pr.dH) *reinterpret_cast<bf16x8*>(pr.dH + (size_t)m * FF + n) = o;
-        }
-      }
-    }
-    // ---- second GEMM: acc[32 rows][128 model] += hidden chunk x weights
     {
       wait_image(i);
       __builtin_amdgcn_s_barrier();
-      if (i + AHEAD < TOTAL) { if (BWD) issue(c + 1, 2, i + AHEAD); else issue(c + 2, 0, i + AHEAD); }
+      if (i + AHEAD < TOTAL) issue(c + 1, 1, i + AHEAD);
+      const unsigned char* himg = smem + (i & (NSLOT - 1)) * SLOT;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          bf16x8 h = frag_n<false>(himg, pw0 + mt * 16 + (lane & 15), tp, lane);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gv = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
+            o[e] = (bf16)((float)h[e] > 0.f ? gv * dscale : 0.f);
+          }
+          hf[mt][tp] = o;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), drsrc,
+                                                 (int)(hoff[mt] + (uint32_t)(c * HC + tp * 32) * 2), 0, 0);
+        }
+      ++i;
+    }
+    {
+      wait_image(i);
+      __builtin_amdgcn_s_barrier();
+      if (i + AHEAD < TOTAL) issue(c + 1, 2, i + AHEAD);
       const unsigned char* img = smem + (i & (NSLOT - 1)) * SLOT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 qf[8];
-        if (BWD) {
-          s16x4 lo[8], hi[8];
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt)
-            frag_t_issue(lo[nt], hi[nt], img, (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks, lane);
-          lds_wait4(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]);
-          lds_wait4(lo[4], hi[4], lo[5], hi[5], lo[6], hi[6], lo[7], hi[7]);
-#pragma unroll
-          for (int nt = 0; nt < 8; ++nt) qf[nt] = frag_join(lo[nt], hi[nt]);
-        } else {
-#pragma unroll
-          for (int nt = 0; nt < 8; ++nt) qf[nt] = qfrag(img, nt, 0, ks);
-        }
+        for (int nt = 0; nt < 8; ++nt) qf[nt] = frag_n<true>(img, qrow(nt), ks, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -252,12 +199,194 @@ __global__ __launch_bounds__(256, 2) void ffn_kernel(const FfnBatch batch) {
     }
   }
 
-  if (!BWD) {
-    epi_ln(acc, pr.epi, p0, pw0, lane);
-  } else {
-    __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
-    epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+  __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
+  epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+}
+
+// ---- forward, software-pipelined across chunks ------------------------------------------------------------
+// One barrier per chunk.  Step c runs, in one straight-line region,
+//   first GEMM of chunk c            (MFMA, image W1(c))
+//   second GEMM of chunk c-1         (MFMA, image W2(c-1), operand = bf16 hidden fragments of the previous step)
+//   bias/ReLU/dropout of chunk c     (VALU, fills the MFMA shadow) -> store + fragments for the next step
+// LDS: two slots per weight (the image being read, the image in flight), filled right after the barrier.
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4];
+  unsigned char* w1s = smem;             // 2 slots
+  unsigned char* w2s = smem + 2 * SLOT;  // 2 slots
+  float* b1s = reinterpret_cast<float*>(smem + 4 * SLOT);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < FFN_MAX_GROUPS; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) g = i;
+  const FfnProb& pr = batch.p[g];
+  const int M = pr.epi.Pn;
+  const int p0 = ((int)blockIdx.x - pr.tile_begin) * BP;
+  const int pw0 = wave * 32;
+  const int q = lane >> 4;
+
+  bf16x8 xf[2][4];
+  uint32_t hoff[2], rseed[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = p0 + pw0 + mt * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < M) v = *reinterpret_cast<const uint4*>(pr.X + (size_t)m * DM + ks * 32 + 8 * q);
+      xf[mt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+    hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;   // byte offset; rows >= M fall outside the descriptor and are dropped
+    rseed[mt] = attn_row_seed(pr.seed, (uint32_t)m);
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    *reinterpret_cast<f32x4*>(b1s + (tid + 256 * i) * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + (tid + 256 * i) * 4);
+  // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
+  const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    offA[j] = src_offset<IMG_W1_FWD>(wave, lane, j, p0, M);
+    offB[j] = src_offset<IMG_W2_FWD>(wave, lane, j, p0, M);
+  }
+  auto issue_w1 = [&](int c) {
+    unsigned char* dst = w1s + (c & 1) * SLOT + wave * (SLOT / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
+  };
+  auto issue_w2 = [&](int c) {
+    unsigned char* dst = w2s + (c & 1) * SLOT + wave * (SLOT / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
+  };
+  auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
+
+  const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
+  const uint32_t thr = drop_threshold(pr.drop_p);
+  const uint32_t lane_pt = (uint32_t)(4 * q) * ATTN_PAIR_MUL;
+
+  f32x4 a1[2][4];
+  bf16x8 hfp[2][2];
+  auto gemm1 = [&](int c) {
+    const unsigned char* img = w1s + (c & 1) * SLOT;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) a1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 qf[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) qf[nt] = frag_n<true>(img, (ks >> 1) * 64 + qrow(nt), ks & 1, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          a1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], xf[mt][ks], a1[mt][nt], 0, 0, 0);
+    }
+  };
+  // Second GEMM of chunk c2 and hidden-chunk arithmetic of chunk c in ONE hand-ordered region: the 32 MFMAs go out
+  // two at a time, each pair followed by one 2-column piece of the bias/ReLU/dropout/convert work (16 pieces), so
+  // the vector ALU runs in the shadow of the matrix pipe.  c2 < 0: arithmetic only.  c < 0: MFMAs only.
+  auto gemm2_hidden = [&](int c2, int c) {
+    const unsigned char* img = w2s + (c2 & 1) * SLOT;
+    const uint32_t chunk_pt = (uint32_t)(c * (HC / 2)) * ATTN_PAIR_MUL;
+    bf16x8 qf[2][4];
+    float bv[2][8];
+    uint32_t hn[2][2][4];
+    if (c2 >= 0) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) qf[0][nt] = frag_n<true>(img, qrow(nt), 0, lane);
+    }
+    if (c >= 0) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) load8f(bv[tp], b1s + c * HC + tp * 32 + 8 * q);
+    }
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      const int ks = grp >> 1, nt0 = (grp & 1) * 4;
+      if (c2 >= 0 && grp + 1 < 4) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          qf[(grp + 1) & 1][nt] = frag_n<true>(img, qrow(((grp + 1) & 1) * 4 + nt), (grp + 1) >> 1, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c2 >= 0) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[mt][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[grp & 1][j], hfp[mt][ks], acc[mt][nt0 + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c >= 0) {
+          const int piece = grp * 4 + j, tp = piece >> 3, mt = (piece >> 2) & 1, e = (piece & 3) * 2;
+          float v0 = a1[mt][2 * tp + (e >> 2)][e & 3], v1 = a1[mt][2 * tp + (e >> 2)][(e & 3) + 1];
+          v0 = fmaxf(v0 + bv[tp][e], 0.f);
+          v1 = fmaxf(v1 + bv[tp][e + 1], 0.f);
+          if (DROP) {
+            const uint32_t hb = attn_pair_bits(rseed[mt] + lane_pt + chunk_pt, (uint32_t)(tp * 16 + (e >> 1)) * ATTN_PAIR_MUL);
+            v0 = ((hb & 0xFFFFu) >= thr) ? v0 * dscale : 0.f;
+            v1 = ((hb >> 16) >= thr) ? v1 * dscale : 0.f;
+          }
+          bf16x2 o2;
+          o2[0] = (bf16)v0;
+          o2[1] = (bf16)v1;
+          hn[mt][tp][e >> 1] = __builtin_bit_cast(uint32_t, o2);
+          if ((piece & 3) == 3) {
+            u32x4 o = {hn[mt][tp][0], hn[mt][tp][1], hn[mt][tp][2], hn[mt][tp][3]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, hrsrc, (int)(hoff[mt] + (uint32_t)(c * HC + tp * 32) * 2), 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (c >= 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          u32x4 o = {hn[mt][tp][0], hn[mt][tp][1], hn[mt][tp][2], hn[mt][tp][3]};
+          hfp[mt][tp] = __builtin_bit_cast(bf16x8, o);
+        }
+    }
+  };
+
+  // prologue: step 0 has no second GEMM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  issue_w1(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  issue_w1(1);
+  issue_w2(0);
+  gemm1(0);
+  gemm2_hidden(-1, 0);
+
+  for (int c = 1; c < NCHUNK; ++c) {
+    // everything older than the 4 hidden-activation stores of the previous step has landed: both images of this step
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + 1 < NCHUNK) issue_w1(c + 1);
+    issue_w2(c);
+    gemm1(c);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm2_hidden(c - 1, c);
+  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  gemm2_hidden(NCHUNK - 1, -1);
+
+  epi_ln(acc, pr.epi, p0, pw0, lane);
 }
 
 int prepare(FfnBatch& b, bool bwd) {
@@ -265,7 +394,7 @@ int prepare(FfnBatch& b, bool bwd) {
   int total = 0;
   for (int i = 0; i < b.n; ++i) {
     FfnProb& p = b.p[i];
-    if ((long)p.epi.Pn * FF >= (1L << 32)) return -1;
+    if (((long)p.epi.Pn + BP) * FF * 2 >= (1L << 31)) return -1;   // 32-bit byte offsets into the hidden activation
     if (p.epi.Pn <= 0 || !p.X || !p.W1 || !p.W2 || !p.H || !p.epi.C) return -1;
     if (!bwd && (!p.b1 || !p.epi.gamma || !p.epi.beta)) return -1;
     if (bwd && (!p.epi.gamma || !p.epi.Z || !p.epi.stats)) return -1;
@@ -281,7 +410,10 @@ int prepare(FfnBatch& b, bool bwd) {
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, false);
   if (total < 0) return MMST_ERR_ARG;
-  hipLaunchKernelGGL((ffn_kernel<false>), dim3(total), dim3(256), 0, stream, b);
+  bool drop = false;
+  for (int i = 0; i < b.n; ++i) drop = drop || b.p[i].drop_p > 0.f;
+  if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_fwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
@@ -289,7 +421,7 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, true);
   if (total < 0) return MMST_ERR_ARG;
-  hipLaunchKernelGGL((ffn_kernel<true>), dim3(total), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(ffn_bwd_kernel, dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

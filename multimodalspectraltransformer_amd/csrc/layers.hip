@@ -113,7 +113,7 @@ inline FfnProb ffn_fwd_prob(const void* x, int M, const void* w1, const float* b
   return f;
 }
 // feed-forward block backward (activations): dx_in = LNbwd_prev(((dzd W2) * mask(h)) W1 + dz)
-inline FfnProb ffn_bwd_prob(const void* dzd, const void* dz, int M, const void* w1, const void* w2, const void* h,
+inline FfnProb ffn_bwd_prob(const void* dzd, const void* dz, int M, const void* w1t, const void* w2t, const void* h,
                             void* dh, float drop_p) {
   FfnProb f;
   memset(&f, 0, sizeof(f));
@@ -121,7 +121,7 @@ inline FfnProb ffn_bwd_prob(const void* dzd, const void* dz, int M, const void* 
   g.Pn = M; g.Qn = D; g.K = FF;
   g.R = (const bf16*)dz; g.ldr = D;
   f.epi = g;
-  f.X = (const bf16*)dzd; f.W1 = (const bf16*)w1; f.W2 = (const bf16*)w2;
+  f.X = (const bf16*)dzd; f.W1 = (const bf16*)w2t; f.W2 = (const bf16*)w1t;
   f.H = (bf16*)h; f.dH = (bf16*)dh; f.drop_p = drop_p;
   return f;
 }
@@ -196,7 +196,7 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
   FfnBatch fb;
   fb.n = n;
   for (int i = 0; i < n; ++i) {
-    FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1, p[i].w_2, a[i].h, w[i].dh, drop_p);
+    FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1t, p[i].w_2t, a[i].h, w[i].dh, drop_p);
     GemmProb& q = f.epi;
     q.C = w[i].dz1; q.ldc = D;
     q.Z = (bf16*)a[i].z1; q.stats = a[i].st1; q.gamma = p[i].g1;
@@ -368,7 +368,7 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
   {
     FfnBatch fb;
     fb.n = 1;
-    FfnProb f = ffn_bwd_prob(w->dzd3, w->dz3, M, p->w_1, p->w_2, a->h, w->dh, drop_p);
+    FfnProb f = ffn_bwd_prob(w->dzd3, w->dz3, M, p->w_1t, p->w_2t, a->h, w->dh, drop_p);
     GemmProb& q = f.epi;
     q.C = w->dz2; q.ldc = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
     q.C2 = dr ? (bf16*)w->dzd2 : nullptr; q.dgamma = g->g2; q.dbeta = g->be2;

@@ -321,6 +321,26 @@ __global__ void cast_kernel(const float* src, bf16* dst, int rows, int cols, int
   dst[(size_t)r * ld_out + c] = (bf16)src[i];
 }
 
+// 64x64 tiles of bf16 matrices transposed through LDS (coalesced on both sides)
+#define TRANSPOSE_MAX 128
+struct TransposeArgs {
+  const bf16* src; bf16* dst;
+  int rows, cols;
+  uint32_t off[TRANSPOSE_MAX];
+};
+__global__ __launch_bounds__(256) void transpose_kernel(const TransposeArgs A) {
+  __shared__ bf16 tile[64][66];
+  const bf16* src = A.src + A.off[blockIdx.z];
+  bf16* dst = A.dst + A.off[blockIdx.z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4)
+    if (r0 + r < A.rows && c0 + tx < A.cols) tile[r][tx] = src[(size_t)(r0 + r) * A.cols + c0 + tx];
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < A.cols && r0 + tx < A.rows) dst[(size_t)(c0 + c) * A.rows + r0 + tx] = tile[tx][c];
+}
+
 int fill_embed_args(EmbedArgs& A, int n, const mmst_embed_group* g, const mmst_embed_shared* s) {
   if (n < 1 || n > MMST_MAX_GROUPS || !g || !s || s->B < 1) return MMST_ERR_ARG;
   A.n = n;
@@ -435,6 +455,16 @@ int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, 
   const long n = (long)rows * cols;
   hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst,
                      rows, cols, ld_out);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_transpose_bf16(const void* src, void* dst, int n, const uint32_t* offsets, int rows, int cols, void* stream) {
+  if (!src || !dst || !offsets || n < 1 || n > TRANSPOSE_MAX || rows < 1 || cols < 1) return MMST_ERR_ARG;
+  TransposeArgs A;
+  A.src = (const bf16*)src; A.dst = (bf16*)dst; A.rows = rows; A.cols = cols;
+  for (int i = 0; i < n; ++i) A.off[i] = offsets[i];
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, A);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

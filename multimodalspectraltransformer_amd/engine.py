@@ -78,6 +78,10 @@ class Arena:
         self.P = torch.zeros(off, dtype=torch.float32, device=device)
         self.G = torch.zeros(off, dtype=torch.float32, device=device)
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        # transposed bf16 copies of the feed-forward weights (same offsets as in Pb), read by the backward pass
+        self.PbT = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.ffn1_offsets = [self.offset[k] for k in order if k.endswith("linear1.weight")]
+        self.ffn2_offsets = [self.offset[k] for k in order if k.endswith("linear2.weight")]
         self.M = None
         self.V = None
         for k in order:
@@ -104,6 +108,18 @@ class Arena:
     def pb(self, k):
         return self.Pb.data_ptr() + 2 * self.offset[k]
 
+    def pbt(self, k):
+        return self.PbT.data_ptr() + 2 * self.offset[k]
+
+    def refresh_transposed(self):
+        """PbT <- transposes of the linear1 / linear2 weights in Pb (one launch per shape, 128 matrices each)."""
+        for offs, rows, cols in ((self.ffn1_offsets, FF, D), (self.ffn2_offsets, D, FF)):
+            for i in range(0, len(offs), 128):
+                part = offs[i:i + 128]
+                arr = (C.c_uint32 * len(part))(*part)
+                L.check(L.lib().mmst_transpose_bf16(C.c_void_p(self.Pb.data_ptr()), C.c_void_p(self.PbT.data_ptr()),
+                                                    len(part), arr, rows, cols, L.stream_ptr()), "mmst_transpose_bf16")
+
     def grad_view(self, k):
         p = self.named[k]
         return self.G[self.offset[k]: self.offset[k] + p.numel()].view(p.shape)
@@ -111,6 +127,7 @@ class Arena:
     def refresh_shadow(self):
         L.check(L.lib().mmst_cast_bf16(C.c_void_p(self.P.data_ptr()), C.c_void_p(self.Pb.data_ptr()), 1,
                                        self.total, self.total, L.stream_ptr()), "mmst_cast_bf16")
+        self.refresh_transposed()
         self.shadow_stale = False
 
     def active_keys(self, mode):
@@ -283,6 +300,8 @@ class Plan:
             key = prefix + k
             setattr(p, f, ar.pb(key) if f.startswith("w_") else ar.p32(key))
             setattr(g, f, ar.g32(key))
+        p.w_1t = ar.pbt(prefix + "linear1.weight")
+        p.w_2t = ar.pbt(prefix + "linear2.weight")
         return p, g
 
     def _dec_params(self, prefix):
@@ -299,6 +318,8 @@ class Plan:
             key = prefix + k
             setattr(p, f, ar.pb(key) if f.startswith("w_") else ar.p32(key))
             setattr(g, f, ar.g32(key))
+        p.w_1t = ar.pbt(prefix + "linear1.weight")
+        p.w_2t = ar.pbt(prefix + "linear2.weight")
         return p, g
 
     def _build_structs(self):

@@ -87,6 +87,7 @@ class FusedAdamW:
                                        C.c_void_p(ar.Pb.data_ptr() + 2 * lo), C.c_long(hi - lo), C.c_float(self.lr),
                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                        C.c_float(self.wd), self.step_count, C.c_float(grad_scale), st), "mmst_adamw")
+        ar.refresh_transposed()
 
     def zero_grad(self):
         self.model._engine.arena.G.zero_()

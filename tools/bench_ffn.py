@@ -19,7 +19,8 @@ for M in Ms:
                              epi=dict(Pn=M, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st, drop_p=0.1, seed=9))])
     dzd = r(M, 128).bfloat16(); dz = r(M, 128).bfloat16(); dz1 = torch.empty_like(z); dzd1 = torch.empty_like(z)
     dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev)
-    bb = ops.ffn_batch([dict(X=dzd, W1=w1, W2=w2, H=h, drop_p=0.1,
+    w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
+    bb = ops.ffn_batch([dict(X=dzd, W1=w2t, W2=w1t, H=h, drop_p=0.1,
                              epi=dict(Pn=M, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, C2=dzd1, dgamma=dg, dbeta=db, drop_p=0.1, seed=5))])
     for name, b, bwd in (("fwd", fb, False), ("bwd", bb, True)):
         for _ in range(3): ops.ffn_launch(b, bwd)
