@@ -34,6 +34,12 @@ int mmst_ffn(const FfnBatch* batch, int backward, void* stream) {
   return backward ? launch_ffn_bwd(b, (hipStream_t)stream) : launch_ffn_fwd(b, (hipStream_t)stream);
 }
 
+// threshold (in 128-row tiles) below which mmst_ffn and the layer entry points use the two-launch path
+int mmst_ffn_config(int fuse_min_tiles) {
+  ffn_set_fuse_min_tiles(fuse_min_tiles);
+  return MMST_OK;
+}
+
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
 int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {
   GemmTap& t = g_gemm_tap;

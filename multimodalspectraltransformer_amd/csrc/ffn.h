@@ -29,3 +29,6 @@ struct FfnBatch {
 
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream);
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream);
+// Launches with fewer 128-row tiles than this run as two grouped GEMM launches instead of the fused kernel
+// (default 96, or the environment variable MMST_FFN_FUSE_MIN_TILES; negative restores the default).
+void ffn_set_fuse_min_tiles(int tiles);

@@ -16,6 +16,8 @@
 // converted to bf16 in place and never touches LDS.
 #include "ffn.h"
 #include "gemm_tile.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -405,11 +407,68 @@ int prepare(FfnBatch& b, bool bwd) {
   return total;
 }
 
+// Below this many 128-row tiles the fused kernels cannot fill the chip (one workgroup walks the whole hidden
+// dimension serially), so short sequences (the decoder) run the block as two grouped GEMM launches whose
+// first GEMM also spreads over the hidden dimension.
+int g_fuse_min_tiles = -1;
+int fuse_min_tiles() {
+  if (g_fuse_min_tiles < 0) {
+    const char* e = getenv("MMST_FFN_FUSE_MIN_TILES");
+    g_fuse_min_tiles = e ? atoi(e) : 96;
+    if (g_fuse_min_tiles < 0) g_fuse_min_tiles = 96;
+  }
+  return g_fuse_min_tiles;
+}
+
+int ffn_fwd_unfused(FfnBatch& b, hipStream_t stream) {
+  GemmBatch g1, g2;
+  g1.n = g2.n = b.n;
+  for (int i = 0; i < b.n; ++i) {
+    const FfnProb& f = b.p[i];
+    GemmProb a;
+    memset(&a, 0, sizeof(a));
+    a.ksplit = 1;
+    a.P = f.X; a.ldp = DM; a.Q = f.W1; a.ldq = DM; a.C = f.H; a.ldc = FF; a.bias = f.b1;
+    a.Pn = f.epi.Pn; a.Qn = FF; a.K = DM;
+    a.flags = GF_RELU; a.drop_p = f.drop_p; a.seed = f.seed;
+    g1.p[i] = a;
+    GemmProb c = f.epi;
+    c.P = f.H; c.ldp = FF; c.Q = f.W2; c.ldq = FF; c.Qn = DM; c.K = FF;
+    g2.p[i] = c;
+  }
+  int rc = launch_gemm(g1, EPI_BIAS, false, false, stream);
+  if (rc) return rc;
+  return launch_gemm(g2, EPI_LN, false, false, stream);
+}
+
+int ffn_bwd_unfused(FfnBatch& b, hipStream_t stream) {
+  GemmBatch g1, g2;
+  g1.n = g2.n = b.n;
+  for (int i = 0; i < b.n; ++i) {
+    const FfnProb& f = b.p[i];
+    if (!f.dH) return MMST_ERR_ARG;
+    GemmProb a;
+    memset(&a, 0, sizeof(a));
+    a.ksplit = 1;
+    a.P = f.X; a.ldp = DM; a.Q = f.W1; a.ldq = DM; a.C = f.dH; a.ldc = FF;   // W1 here = linear2^T [2048][128]
+    a.R = f.H; a.ldr = FF; a.drop_p = f.drop_p;
+    a.Pn = f.epi.Pn; a.Qn = FF; a.K = DM;
+    g1.p[i] = a;
+    GemmProb c = f.epi;
+    c.P = f.dH; c.ldp = FF; c.Q = f.W2; c.ldq = FF; c.Qn = DM; c.K = FF;      // W2 here = linear1^T [128][2048]
+    g2.p[i] = c;
+  }
+  int rc = launch_gemm(g1, EPI_DRELU, false, false, stream);
+  if (rc) return rc;
+  return launch_gemm(g2, EPI_LNBWD, false, false, stream);
+}
+
 }  // namespace
 
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, false);
   if (total < 0) return MMST_ERR_ARG;
+  if (total < fuse_min_tiles()) return ffn_fwd_unfused(b, stream);
   bool drop = false;
   for (int i = 0; i < b.n; ++i) drop = drop || b.p[i].drop_p > 0.f;
   if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
@@ -421,7 +480,10 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, true);
   if (total < 0) return MMST_ERR_ARG;
+  if (total < fuse_min_tiles()) return ffn_bwd_unfused(b, stream);
   hipLaunchKernelGGL(ffn_bwd_kernel, dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
+
+void ffn_set_fuse_min_tiles(int tiles) { g_fuse_min_tiles = tiles; }

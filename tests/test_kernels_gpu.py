@@ -197,6 +197,90 @@ def test_gemm_dropout_consistency():
     close(dzd, dz.float() * keep / (1 - p), rtol=1e-2, atol=1e-2)
 
 
+# --------------------------------------------------------------------------- fused feed-forward block
+def ffn_keep_mask(seed, M, N, p):
+    """numpy restatement of the row-seeded hidden dropout of the fused forward kernel (csrc/common.h)."""
+    m_, n_ = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    return attn_keep_mask(seed, m_.reshape(-1), n_.reshape(-1), p).reshape(M, N)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("M,groups,p", [(300, 1, 0.0), (1000, 2, 0.1), (129, 3, 0.0)])
+def test_ffn_fwd_bwd(fused, M, groups, p):
+    """y = LN(x + drop(W2 drop(relu(W1 x + b1)) + b2)) and its activation-gradient pass, fused kernels and the
+    two-launch path, against fp32 torch math on the same bf16 operands (hidden dropout mask taken from h)."""
+    L.check(L.lib().mmst_ffn_config(0 if fused else 1 << 20), "cfg")
+    try:
+        fw, bw, keepers = [], [], []
+        for gi in range(groups):
+            Mg = M + 17 * gi
+            sd = 10 * gi
+            x = bf(rnd(Mg, 128, seed=sd + 1))
+            w1, w2 = bf(rnd(2048, 128, scale=0.08, seed=sd + 2)), bf(rnd(128, 2048, scale=0.03, seed=sd + 3))
+            b1, b2 = 0.1 * rnd(2048, seed=sd + 4), 0.1 * rnd(128, seed=sd + 5)
+            gam, bet = 1 + 0.1 * rnd(128, seed=sd + 6), 0.1 * rnd(128, seed=sd + 7)
+            h = torch.full((Mg, 2048), float("nan"), dtype=torch.bfloat16, device=DEV)
+            y = torch.empty(Mg, 128, dtype=torch.bfloat16, device=DEV)
+            z = torch.empty_like(y)
+            st = torch.empty(Mg, 2, device=DEV)
+            fw.append(dict(X=x, W1=w1, W2=w2, b1=b1, H=h, drop_p=p, seed=100 + gi,
+                           epi=dict(Pn=Mg, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st,
+                                    drop_p=p, seed=200 + gi)))
+            dzd, dz = bf(rnd(Mg, 128, seed=sd + 8)), bf(rnd(Mg, 128, seed=sd + 9))
+            dz1 = torch.empty_like(y)
+            dh = torch.empty_like(h)
+            dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+            # backward epilogue = LayerNorm backward of an EARLIER norm: reuse (z, st, gam) of this call as its saved state
+            bw.append(dict(X=dzd, W1=w2.t().contiguous(), W2=w1.t().contiguous(), H=h, dH=dh, drop_p=p,
+                           epi=dict(Pn=Mg, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=db)))
+            keepers.append((x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db))
+        ops.ffn_launch(ops.ffn_batch(fw), backward=False)
+        ops.ffn_launch(ops.ffn_batch(bw), backward=True)
+        torch.cuda.synchronize()
+        for gi, (x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db) in enumerate(keepers):
+            Mg = x.shape[0]
+            pre = torch.relu(x.float() @ w1.float().t() + b1)
+            if p > 0:
+                if fused:
+                    keep = torch.from_numpy(ffn_keep_mask(100 + gi, Mg, 2048, p)).to(DEV)
+                else:
+                    keep = torch.from_numpy(keep_mask(100 + gi, np.arange(Mg * 2048), p).reshape(Mg, 2048)).to(DEV)
+                assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+                pre = pre * keep / (1 - p)
+            close(h, pre)
+            out = h.float() @ w2.float().t() + b2
+            if p > 0:
+                keep2 = torch.from_numpy(keep_mask(200 + gi, np.arange(Mg * 128), p).reshape(Mg, 128)).to(DEV)
+                out = out * keep2 / (1 - p)
+            zref = x.float() + out
+            close(z, zref)
+            close(y, torch.nn.functional.layer_norm(z.float(), (128,), gam, bet, 1e-5))
+            # backward
+            dh_ref = (dzd.float() @ w2.float()) * (h.float() > 0) / (1 - p)
+            close(dh, dh_ref)
+            dy = dh.float() @ w1.float() + dz.float()
+            zr = z.float().detach().requires_grad_(True)
+            gr = gam.clone().requires_grad_(True)
+            torch.nn.functional.layer_norm(zr, (128,), gr, bet, 1e-5).backward(dy)
+            close(dz1, zr.grad, rtol=3e-2, atol=3e-2)
+            close(dg, gr.grad, rtol=2e-2, atol=2e-2)
+            close(db, dy.sum(0), rtol=2e-2, atol=2e-2)
+    finally:
+        L.check(L.lib().mmst_ffn_config(-1), "cfg")
+
+
+def test_transpose_bf16():
+    import ctypes as C
+    src = bf(rnd(3 * 2048 * 128 + 64, seed=5))
+    dst = torch.zeros_like(src)
+    offs = [0, 2048 * 128 + 64, 2 * 2048 * 128 + 64]
+    arr = (C.c_uint32 * 3)(*offs)
+    L.check(L.lib().mmst_transpose_bf16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 3, arr, 2048, 128,
+                                        L.stream_ptr()), "transpose")
+    for o in offs:
+        assert torch.equal(dst[o:o + 2048 * 128].view(128, 2048), src[o:o + 2048 * 128].view(2048, 128).t())
+
+
 # --------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, bias, causal, hd, keep=None, p=0.0):
     """q (B,T,H,hd) fp32 etc.  Returns O (B,T,H,hd)."""
