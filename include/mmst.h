@@ -112,6 +112,8 @@ typedef struct {
   void* h; void* z3; float* st3;
   int B, T, L;
   int kv_ready; /* nonzero: kvc already holds this layer's K/V projection of mem (decode loops reuse it) */
+  float* ffn_ws; /* optional fp32 workspace [8][B*T][128]: lets the feed-forward block of a SHORT sequence split its
+                    hidden dimension over up to 8 workgroups per row tile (NULL: no split) */
 } mmst_dec_acts;
 
 typedef struct {

@@ -29,6 +29,7 @@ class GemmProb(C.Structure):
         ("cS", C.c_int), ("cL", C.c_int), ("coff", C.c_int), ("rS", C.c_int), ("rL", C.c_int), ("roff", C.c_int),
         ("ksplit", C.c_int), ("tile_begin", C.c_int),
         ("ptiles", C.c_int), ("qtiles", C.c_int),
+        ("acc_init", C.c_void_p), ("acc_slabs", C.c_int),
     ]
 
 
@@ -56,8 +57,8 @@ class AttnBatch(C.Structure):
 
 class FfnProb(C.Structure):
     _fields_ = [("epi", GemmProb), ("X", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("b1", C.c_void_p),
-                ("H", C.c_void_p), ("dH", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
-                ("tile_begin", C.c_int)]
+                ("H", C.c_void_p), ("dH", C.c_void_p), ("ws", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
+                ("tile_begin", C.c_int), ("hsplit", C.c_int)]
 
 
 class FfnBatch(C.Structure):
@@ -140,7 +141,7 @@ class DecGrads(C.Structure):
 class DecActs(C.Structure):
     _fields_ = _ptrs("x", "y", "mem", "mem_bias", "qkv", "attn1", "lse1", "z1", "st1", "x1", "qc", "kvc", "attn2",
                      "lse2", "z2", "st2", "x2", "h", "z3", "st3") + [
-        ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int)]
+        ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int), ("ffn_ws", C.c_void_p)]
 
 
 class DecBwd(C.Structure):

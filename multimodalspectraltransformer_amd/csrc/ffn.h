@@ -8,6 +8,7 @@
 #include "gemm.h"
 
 #define FFN_MAX_GROUPS 6
+#define FFN_MAX_HSPLIT 8
 
 struct FfnProb {
   GemmProb epi;        // final row epilogue (EPI_LN forward / EPI_LNBWD backward); Pn = rows, Qn = 128
@@ -17,9 +18,11 @@ struct FfnProb {
   const float* b1;     // [2048] (forward)
   bf16* H;             // [M][2048] hidden activation after ReLU and dropout: written (forward), read (backward)
   bf16* dH;            // optional [M][2048] output of the backward kernel (gradient at the hidden pre-activation)
+  float* ws;           // optional fp32 [FFN_MAX_HSPLIT][M][128]: enables the hidden-dimension split for few row tiles
   float drop_p;        // dropout on the hidden activation
   uint32_t seed;
   int tile_begin;      // filled by the launcher
+  int hsplit;          // filled by the launcher: workgroups per row tile (each walks 2048/hsplit hidden columns)
 };
 
 struct FfnBatch {

@@ -62,6 +62,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //   dh = g * mask(h)  mask = saved hidden activation > 0 (ReLU and dropout at once), h tile by LDS-DMA
 //   dx += dh W1       second GEMM, weight image from W1^T [128][2048]
 // Three images per chunk through a ring of four slots, three images ahead, one barrier per image.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT];
 
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) g = i;
   const FfnProb& pr = batch.p[g];
   const int M = pr.epi.Pn;
-  const int p0 = ((int)blockIdx.x - pr.tile_begin) * BP;
+  const int local = (int)blockIdx.x - pr.tile_begin;
+  const int hsplit = SPLIT ? pr.hsplit : 1;
+  const int p0 = (local / hsplit) * BP;
+  const int hs = local % hsplit;                      // this workgroup walks hidden chunks [c0, c1)
+  const int c0 = SPLIT ? hs * NCHUNK / hsplit : 0, c1 = SPLIT ? (hs + 1) * NCHUNK / hsplit : NCHUNK;
   const int pw0 = wave * 32;
   const int q = lane >> 4;
 
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int NIMG = 3, TOTAL = NCHUNK * NIMG;
+  constexpr int NIMG = 3;
+  const int TOTAL = (c1 - c0) * NIMG;
   uint32_t offA[4], offB[4], offH[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -130,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
   auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
 
-  issue(0, 0, 0);
-  issue(0, 1, 1);
-  issue(0, 2, 2);
+  issue(c0, 0, 0);
+  issue(c0, 1, 1);
+  issue(c0, 2, 2);
 
-  for (int c = 0; c < NCHUNK; ++c) {
-    int i = c * NIMG;
+  for (int c = c0; c < c1; ++c) {
+    int i = (c - c0) * NIMG;
     f32x4 a1[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -201,8 +207,12 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
     }
   }
 
-  __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
-  epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+  if constexpr (SPLIT) {   // partial sums; the row epilogue runs as a second launch over all slabs
+    store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
+  } else {
+    __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
+    epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+  }
 }
 
 // ---- forward, software-pipelined across chunks ------------------------------------------------------------
@@ -225,7 +235,10 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) g = i;
   const FfnProb& pr = batch.p[g];
   const int M = pr.epi.Pn;
-  const int p0 = ((int)blockIdx.x - pr.tile_begin) * BP;
+  const int local = (int)blockIdx.x - pr.tile_begin;
+  const int p0 = (local / pr.hsplit) * BP;
+  const int hs = local % pr.hsplit;                   // this workgroup walks hidden chunks [c0, c1)
+  const int c0 = hs * NCHUNK / pr.hsplit, c1 = (hs + 1) * NCHUNK / pr.hsplit;
   const int pw0 = wave * 32;
   const int q = lane >> 4;
 
@@ -366,19 +379,19 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   // prologue: step 0 has no second GEMM
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  issue_w1(0);
+  issue_w1(c0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  issue_w1(1);
-  issue_w2(0);
-  gemm1(0);
-  gemm2_hidden(-1, 0);
+  if (c0 + 1 < c1) issue_w1(c0 + 1);
+  issue_w2(c0);
+  gemm1(c0);
+  gemm2_hidden(-1, c0);
 
-  for (int c = 1; c < NCHUNK; ++c) {
+  for (int c = c0 + 1; c < c1; ++c) {
     // everything older than the 4 hidden-activation stores of the previous step has landed: both images of this step
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (c + 1 < NCHUNK) issue_w1(c + 1);
+    if (c + 1 < c1) issue_w1(c + 1);
     issue_w2(c);
     gemm1(c);
     __builtin_amdgcn_sched_barrier(0);
@@ -386,14 +399,16 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   }
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  gemm2_hidden(NCHUNK - 1, -1);
+  gemm2_hidden(c1 - 1, -1);
 
-  epi_ln(acc, pr.epi, p0, pw0, lane);
+  if (pr.hsplit > 1) store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
+  else epi_ln(acc, pr.epi, p0, pw0, lane);
 }
 
 int prepare(FfnBatch& b, bool bwd) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return -1;
-  int total = 0;
+  int tiles = 0;
+  bool have_ws = true;
   for (int i = 0; i < b.n; ++i) {
     FfnProb& p = b.p[i];
     if (((long)p.epi.Pn + BP) * FF * 2 >= (1L << 31)) return -1;   // 32-bit byte offsets into the hidden activation
@@ -401,10 +416,34 @@ int prepare(FfnBatch& b, bool bwd) {
     if (!bwd && (!p.b1 || !p.epi.gamma || !p.epi.beta)) return -1;
     if (bwd && (!p.epi.gamma || !p.epi.Z || !p.epi.stats)) return -1;
     p.epi.Qn = DM;
+    tiles += (p.epi.Pn + BP - 1) / BP;
+    have_ws = have_ws && p.ws != nullptr;
+  }
+  // few row tiles: split the hidden dimension over up to FFN_MAX_HSPLIT workgroups per tile (needs the workspace)
+  int hsplit = 1;
+  if (have_ws)
+    while (hsplit < FFN_MAX_HSPLIT && tiles * hsplit * 2 <= 256) hsplit *= 2;
+  int total = 0;
+  for (int i = 0; i < b.n; ++i) {
+    FfnProb& p = b.p[i];
+    p.hsplit = hsplit;
     p.tile_begin = total;
-    total += (p.epi.Pn + BP - 1) / BP;
+    total += ((p.epi.Pn + BP - 1) / BP) * hsplit;
   }
   return total;
+}
+
+// second stage of a hidden-split launch: sum the fp32 slabs and run the row epilogue
+int row_epilogue(const FfnBatch& b, int epi, hipStream_t stream) {
+  GemmBatch g;
+  g.n = b.n;
+  for (int i = 0; i < b.n; ++i) {
+    GemmProb c = b.p[i].epi;
+    c.P = nullptr; c.Q = nullptr; c.K = 0; c.ldp = 8; c.ldq = 8; c.Qn = DM;
+    c.acc_init = b.p[i].ws; c.acc_slabs = b.p[i].hsplit;
+    g.p[i] = c;
+  }
+  return launch_gemm(g, epi, false, false, stream);
 }
 
 // Below this many 128-row tiles the fused kernels cannot fill the chip (one workgroup walks the whole hidden
@@ -468,21 +507,26 @@ int ffn_bwd_unfused(FfnBatch& b, hipStream_t stream) {
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, false);
   if (total < 0) return MMST_ERR_ARG;
-  if (total < fuse_min_tiles()) return ffn_fwd_unfused(b, stream);
+  const bool split = b.p[0].hsplit > 1;
+  if (!split && total < fuse_min_tiles()) return ffn_fwd_unfused(b, stream);
   bool drop = false;
   for (int i = 0; i < b.n; ++i) drop = drop || b.p[i].drop_p > 0.f;
   if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
   else hipLaunchKernelGGL((ffn_fwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
+  if (split) return row_epilogue(b, EPI_LN, stream);
   return MMST_OK;
 }
 
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, true);
   if (total < 0) return MMST_ERR_ARG;
-  if (total < fuse_min_tiles()) return ffn_bwd_unfused(b, stream);
-  hipLaunchKernelGGL(ffn_bwd_kernel, dim3(total), dim3(256), 0, stream, b);
+  const bool split = b.p[0].hsplit > 1;
+  if (!split && total < fuse_min_tiles()) return ffn_bwd_unfused(b, stream);
+  if (split) hipLaunchKernelGGL((ffn_bwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_bwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
+  if (split) return row_epilogue(b, EPI_LNBWD, stream);
   return MMST_OK;
 }
 

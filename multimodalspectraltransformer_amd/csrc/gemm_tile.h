@@ -127,6 +127,38 @@ __device__ __forceinline__ void drop8(float (&v)[8], uint32_t seed, uint32_t idx
   }
 }
 
+// ---- fp32 partial sums of a row-owning accumulator (4x1 wave layout): slab s holds [rows][128] floats ----
+__device__ __forceinline__ void store_slab(const f32x4 (&acc)[2][8], float* slab, int rows, int p0, int pw0, int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = p0 + pw0 + mt * 16 + (lane & 15);
+    if (m >= rows) continue;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      float* d = slab + (size_t)m * 128 + tp * 32 + 8 * q;
+      *reinterpret_cast<f32x4*>(d) = acc[mt][2 * tp];
+      *reinterpret_cast<f32x4*>(d + 4) = acc[mt][2 * tp + 1];
+    }
+  }
+}
+__device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs, int n, int rows, int p0, int pw0, int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = p0 + pw0 + mt * 16 + (lane & 15);
+    if (m >= rows) continue;
+    for (int s = 0; s < n; ++s) {
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        const float* d = slabs + ((size_t)s * rows + m) * 128 + tp * 32 + 8 * q;
+        acc[mt][2 * tp] += *reinterpret_cast<const f32x4*>(d);
+        acc[mt][2 * tp + 1] += *reinterpret_cast<const f32x4*>(d + 4);
+      }
+    }
+  }
+}
+
 // ---- LayerNorm forward on a 4x1 wave layout: acc[mt][nt] holds rows p0+pw0+mt*16+(lane&15), all 128 columns.
 // z = R + drop(acc + bias); C = LN(z) (row remap cS/cL/coff); Z = z; stats = (mean, rstd).
 __device__ __forceinline__ void epi_ln(f32x4 (&acc)[2][8], const GemmProb& pr, int p0, int pw0, int lane) {

@@ -350,6 +350,7 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
     fb.n = 1;
     fb.p[0] = ffn_fwd_prob(a->x2, M, p->w_1, p->b_1, p->w_2, p->b_2, p->g3, p->be3, a->h, a->z3, a->st3, a->y, drop_p,
                            seed + 4, seed + 5);
+    fb.p[0].ws = a->ffn_ws;
     RUN(launch_ffn_fwd(fb, st));
   }
   return MMST_OK;
@@ -373,6 +374,7 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
     q.C = w->dz2; q.ldc = D; q.Z = (bf16*)a->z2; q.stats = a->st2; q.gamma = p->g2;
     q.C2 = dr ? (bf16*)w->dzd2 : nullptr; q.dgamma = g->g2; q.dbeta = g->be2;
     q.drop_p = drop_p; q.seed = seed + 3;
+    f.ws = a->ffn_ws;
     fb.p[0] = f;
     RUN(launch_ffn_bwd(fb, st));
   }

@@ -192,7 +192,13 @@ class _Carver:
             h[3] = self.buf[h[0]].data_ptr() + h[1] * self.buf[h[0]].element_size()
 
     def view(self, h, *shape):
-        return self.buf[h[0]][h[1]: h[1] + h[2]].view(*shape)
+        """Tensor view of the leading prod(shape) elements of a carved buffer (buffers may hold spare capacity)."""
+        n = 1
+        for d in shape:
+            n *= d
+        if n > h[2]:
+            raise L.MMSTError(f"view of {n} elements exceeds the buffer's {h[2]}")
+        return self.buf[h[0]][h[1]: h[1] + n].view(*shape)
 
 
 def _P(h):
@@ -204,6 +210,8 @@ class Plan:
 
     def __init__(self, eng, B, T, mode):
         self.eng, self.B, self.T, self.mode = eng, B, T, mode
+        # decoder buffers are carved for this many target positions: a full-length decode fits every plan
+        self.cap_T = max(T, 1, int(eng.model.max_len))
         m = eng.model
         ar = eng.arena
         nl, ndl = m.num_encoder_layers, m.num_decoder_layers
@@ -244,7 +252,7 @@ class Plan:
         self.cross_acts = [enc_acts(B * Lm, 4, Lm) for _ in range(nl)]
         self.mean = cv.take(B * D)
         self.fingerprint = cv.take(B * m.fingerprint_size, f32)
-        Tm = max(T, 1)
+        Tm = self.cap_T
         M = B * Tm
         self.tok = cv.take((m.max_len + 1) * B, torch.int64)
         self.trg_emb = cv.take(M * D)
@@ -255,6 +263,7 @@ class Plan:
                 st1=cv.take(M * 2, f32), x1=cv.take(M * D), qc=cv.take(M * D), kvc=cv.take(B * Lm * 2 * D),
                 attn2=cv.take(M * D), lse2=cv.take(B * 16 * Tm, f32), z2=cv.take(M * D), st2=cv.take(M * 2, f32),
                 x2=cv.take(M * D), h=cv.take(M * FF), z3=cv.take(M * D), st3=cv.take(M * 2, f32), y=cv.take(M * D)))
+        self.ffn_ws = cv.take(8 * M * D, f32)   # hidden-split partial sums of the decoder feed-forward blocks
         self.logits = cv.take(M * VPAD, f32)
         self.dlogits = cv.take(M * VPAD)
         self.loss = cv.take(1, f32)
@@ -400,6 +409,7 @@ class Plan:
                       "z3", "st3"):
                 setattr(a, f, _P(acts[f]))
             a.B, a.T, a.L = B, T, Lm
+            a.ffn_ws = _P(self.ffn_ws)
             w, sc = L.DecBwd(), self.dec_bwd[l]
             w.dz3, w.dzd3 = _P(sc["dz"]), _P(sc["dzd"])
             self.dec_dzd.append((w.dz3, w.dzd3))
@@ -419,6 +429,8 @@ class Plan:
 
     def set_T(self, T, kv_ready=0):
         """Decode loops re-run the decoder with a growing prefix in the same buffers."""
+        if T > self.cap_T:
+            raise L.MMSTError(f"decode length {T} exceeds the plan's capacity of {self.cap_T} target positions")
         for a in self.dec_a:
             a.T = T
             a.kv_ready = kv_ready
@@ -645,10 +657,12 @@ class Engine:
             weights_after_data()
             L.check(lib.mmst_decoder_layer_bwd_weights(C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]), C.byref(w),
                                                        C.c_float(p_drop), wst), "mmst_decoder_layer_bwd_weights")
+        # target-embedding gradients only feed parameters: off the critical path
+        weights_after_data()
         L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
                                        C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
                                        B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
-                                       st), "mmst_trg_embed_bwd")
+                                       wst), "mmst_trg_embed_bwd")
         if on_segment:
             on_segment("decoder")
         # cross encoder

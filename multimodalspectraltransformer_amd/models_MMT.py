@@ -360,7 +360,7 @@ class MultimodalTransformer(nn.Module):
         mode = self.config.training_mode
         first = next(batch["src_" + t] for t in ("1H", "13C", "HSQC", "COSY") if t in mode)
         B = first.shape[0]
-        pl = eng.plan(B, T if T else 63, mode)
+        pl = eng.plan(B, T if T else self.max_len, mode)   # no target: room for a full-length decode
         eng.encode(pl, batch, self.training)
         return pl
 

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib as L
 
-_PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", "dgamma", "dbeta", "dbias")
+_PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", "dgamma", "dbeta", "dbias", "acc_init")
 
 
 def gemm_batch(groups):
@@ -65,7 +65,7 @@ def attn_bwd_launch(batch):
     L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
 
 
-_FPTR = ("X", "W1", "W2", "b1", "H", "dH")
+_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws")
 
 
 def ffn_batch(groups):

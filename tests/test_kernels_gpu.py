@@ -204,7 +204,7 @@ def ffn_keep_mask(seed, M, N, p):
     return attn_keep_mask(seed, m_.reshape(-1), n_.reshape(-1), p).reshape(M, N)
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "split"])
 @pytest.mark.parametrize("M,groups,p", [(300, 1, 0.0), (1000, 2, 0.1), (129, 3, 0.0)])
 def test_ffn_fwd_bwd(fused, M, groups, p):
     """y = LN(x + drop(W2 drop(relu(W1 x + b1)) + b2)) and its activation-gradient pass, fused kernels and the
@@ -223,7 +223,8 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
             y = torch.empty(Mg, 128, dtype=torch.bfloat16, device=DEV)
             z = torch.empty_like(y)
             st = torch.empty(Mg, 2, device=DEV)
-            fw.append(dict(X=x, W1=w1, W2=w2, b1=b1, H=h, drop_p=p, seed=100 + gi,
+            ws = torch.full((8, Mg, 128), float("nan"), device=DEV) if fused == "split" else None
+            fw.append(dict(X=x, W1=w1, W2=w2, b1=b1, H=h, ws=ws, drop_p=p, seed=100 + gi,
                            epi=dict(Pn=Mg, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st,
                                     drop_p=p, seed=200 + gi)))
             dzd, dz = bf(rnd(Mg, 128, seed=sd + 8)), bf(rnd(Mg, 128, seed=sd + 9))
@@ -231,7 +232,7 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
             dh = torch.empty_like(h)
             dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
             # backward epilogue = LayerNorm backward of an EARLIER norm: reuse (z, st, gam) of this call as its saved state
-            bw.append(dict(X=dzd, W1=w2.t().contiguous(), W2=w1.t().contiguous(), H=h, dH=dh, drop_p=p,
+            bw.append(dict(X=dzd, W1=w2.t().contiguous(), W2=w1.t().contiguous(), H=h, dH=dh, ws=ws, drop_p=p,
                            epi=dict(Pn=Mg, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=db)))
             keepers.append((x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db))
         ops.ffn_launch(ops.ffn_batch(fw), backward=False)

@@ -6,6 +6,8 @@ args = sys.argv[1:]
 if args and args[0].endswith(".so"):
     L.LIB_PATH = os.path.abspath(args.pop(0))
 from multimodalspectraltransformer_amd import ops
+if args and args[0].startswith("fuse="):
+    L.check(L.lib().mmst_ffn_config(int(args.pop(0)[5:])), "cfg")
 Ms = [int(a) for a in args] or [37248, 4032]
 dev = "cuda"
 for M in Ms:
@@ -20,7 +22,8 @@ for M in Ms:
     dzd = r(M, 128).bfloat16(); dz = r(M, 128).bfloat16(); dz1 = torch.empty_like(z); dzd1 = torch.empty_like(z)
     dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev)
     w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
-    bb = ops.ffn_batch([dict(X=dzd, W1=w2t, W2=w1t, H=h, drop_p=0.1,
+    dh = torch.empty_like(h)
+    bb = ops.ffn_batch([dict(X=dzd, W1=w2t, W2=w1t, H=h, dH=dh, drop_p=0.1,
                              epi=dict(Pn=M, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, C2=dzd1, dgamma=dg, dbeta=db, drop_p=0.1, seed=5))])
     for name, b, bwd in (("fwd", fb, False), ("bwd", bb, True)):
         for _ in range(3): ops.ffn_launch(b, bwd)
