@@ -29,7 +29,6 @@ class GemmProb(C.Structure):
         ("cS", C.c_int), ("cL", C.c_int), ("coff", C.c_int), ("rS", C.c_int), ("rL", C.c_int), ("roff", C.c_int),
         ("ksplit", C.c_int), ("tile_begin", C.c_int),
         ("ptiles", C.c_int), ("qtiles", C.c_int),
-        ("acc_init", C.c_void_p), ("acc_slabs", C.c_int),
     ]
 
 

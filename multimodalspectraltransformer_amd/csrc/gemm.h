@@ -36,9 +36,6 @@ struct GemmProb {
   int ksplit;      // number of K slices (EPI_ATOMIC only), >= 1
   int tile_begin;  // filled by the launcher
   int ptiles, qtiles;
-  // Row epilogues (EPI_LN / EPI_LNBWD) only: fp32 partial sums [acc_slabs][Pn][128] added to the accumulator
-  // before the epilogue (K may be 0) -- the second stage of a computation split over several workgroups.
-  const float* acc_init; int acc_slabs;
 };
 
 #define GEMM_MAX_GROUPS 16

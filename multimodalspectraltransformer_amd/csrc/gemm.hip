@@ -214,9 +214,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     }
   }
 
-  if constexpr (ROWEPI) {
-    if (pr.acc_init) add_slabs(acc, pr.acc_init, pr.acc_slabs, pr.Pn, p0, pw0, lane);
-  }
   if constexpr (EPI == EPI_LN) {
     if constexpr (ROWEPI) epi_ln(acc, pr, p0, pw0, lane);
   }

@@ -148,12 +148,19 @@ __device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs
   for (int mt = 0; mt < 2; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
     if (m >= rows) continue;
-    for (int s = 0; s < n; ++s) {
 #pragma unroll
-      for (int tp = 0; tp < 4; ++tp) {
-        const float* d = slabs + ((size_t)s * rows + m) * 128 + tp * 32 + 8 * q;
-        acc[mt][2 * tp] += *reinterpret_cast<const f32x4*>(d);
-        acc[mt][2 * tp + 1] += *reinterpret_cast<const f32x4*>(d + 4);
+    for (int tp = 0; tp < 4; ++tp) {
+      // all slabs of this 8-column piece in flight at once (n <= 8), then summed
+      f32x4 lo[8], hi[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float* d = slabs + ((size_t)(s < n ? s : 0) * rows + m) * 128 + tp * 32 + 8 * q;
+        lo[s] = *reinterpret_cast<const f32x4*>(d);
+        hi[s] = *reinterpret_cast<const f32x4*>(d + 4);
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s < n) { acc[mt][2 * tp] += lo[s]; acc[mt][2 * tp + 1] += hi[s]; }
       }
     }
   }

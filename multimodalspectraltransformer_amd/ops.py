@@ -9,7 +9,7 @@ import torch
 
 from . import _lib as L
 
-_PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", "dgamma", "dbeta", "dbias", "acc_init")
+_PTR_FIELDS = ("P", "Q", "C", "bias", "R", "gamma", "beta", "Z", "stats", "C2", "dgamma", "dbeta", "dbias")
 
 
 def gemm_batch(groups):
