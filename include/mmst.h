@@ -86,8 +86,8 @@ int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads
  * w's scratch must stay untouched until _weights has run. */
 int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                                 const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
-int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
-                                   float drop_p, void* stream);
+int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                   const mmst_enc_bwd* w, float drop_p, void* stream);
 
 /* ---- one post-norm decoder layer == nn.TransformerDecoderLayer(d_model=128, nhead=16) (:539-541) ---- */
 typedef struct {

@@ -64,6 +64,15 @@ class FfnBatch(C.Structure):
     _fields_ = [("n", C.c_int), ("p", FfnProb * MAX_GROUPS)]
 
 
+class FfnWgradProb(C.Structure):
+    _fields_ = _P8 = [(n, C.c_void_p) for n in ("dZ", "H", "X", "W2T", "dW1", "db1", "dW2", "db2")] + [
+        ("M", C.c_int), ("drop_p", C.c_float)]
+
+
+class FfnWgradBatch(C.Structure):
+    _fields_ = [("n", C.c_int), ("p", FfnWgradProb * MAX_GROUPS)]
+
+
 _lib = None
 
 
@@ -80,7 +89,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         if _lib.mmst_sizeof_gemm_batch() != C.sizeof(GemmBatch) or \
                 _lib.mmst_sizeof_attn_batch() != C.sizeof(AttnBatch) or \
-                _lib.mmst_sizeof_ffn_batch() != C.sizeof(FfnBatch):
+                _lib.mmst_sizeof_ffn_batch() != C.sizeof(FfnBatch) or \
+                _lib.mmst_sizeof_ffn_wgrad_batch() != C.sizeof(FfnWgradBatch):
             raise MMSTError("struct layout mismatch between _lib.py and libmmst.so")
     return _lib
 

@@ -34,6 +34,13 @@ int mmst_ffn(const FfnBatch* batch, int backward, void* stream) {
   return backward ? launch_ffn_bwd(b, (hipStream_t)stream) : launch_ffn_fwd(b, (hipStream_t)stream);
 }
 
+// feed-forward weight gradients with the hidden gradient recomputed in the kernel (accumulating)
+int mmst_ffn_wgrad(const FfnWgradBatch* batch, void* stream) {
+  if (!batch) return MMST_ERR_ARG;
+  FfnWgradBatch b = *batch;
+  return launch_ffn_wgrad(b, (hipStream_t)stream);
+}
+
 // threshold (in 128-row tiles) below which mmst_ffn and the layer entry points use the two-launch path
 int mmst_ffn_config(int fuse_min_tiles) {
   ffn_set_fuse_min_tiles(fuse_min_tiles);
@@ -85,5 +92,6 @@ int mmst_tap_read(float* total_ms, int* count, double* flops, double* bytes, cha
 int mmst_sizeof_gemm_batch() { return (int)sizeof(GemmBatch); }
 int mmst_sizeof_attn_batch() { return (int)sizeof(AttnBatch); }
 int mmst_sizeof_ffn_batch() { return (int)sizeof(FfnBatch); }
+int mmst_sizeof_ffn_wgrad_batch() { return (int)sizeof(FfnWgradBatch); }
 int mmst_version() { return 1; }
 }

@@ -30,8 +30,26 @@ struct FfnBatch {
   FfnProb p[FFN_MAX_GROUPS];
 };
 
+// Weight gradients of the block, recomputing the hidden gradient (ffn_wgrad.hip).  Accumulates (fp32 atomics).
+struct FfnWgradProb {
+  const bf16* dZ;      // [M][128] gradient of the block output (after the output dropout mask)
+  const bf16* H;       // [M][2048] saved hidden activation
+  const bf16* X;       // [M][128] block input
+  const bf16* W2T;     // [2048][128] transpose of linear2
+  float* dW1; float* db1;   // [2048][128], [2048]
+  float* dW2; float* db2;   // [128][2048], [128]
+  int M;
+  float drop_p;
+};
+struct FfnWgradBatch {
+  int n;
+  FfnWgradProb p[FFN_MAX_GROUPS];
+};
+int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream);
+
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream);
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream);
 // Launches with fewer 128-row tiles than this run as two grouped GEMM launches instead of the fused kernel
 // (default 96, or the environment variable MMST_FFN_FUSE_MIN_TILES; negative restores the default).
 void ffn_set_fuse_min_tiles(int tiles);
+int ffn_fuse_min_tiles();

@@ -547,3 +547,4 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
 }
 
 void ffn_set_fuse_min_tiles(int tiles) { g_fuse_min_tiles = tiles; }
+int ffn_fuse_min_tiles() { return fuse_min_tiles(); }

@@ -195,8 +195,12 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
   // feed-forward block backward fused with norm1 backward: dz1 = LNbwd(((dzd2 W2) * mask(h)) W1 + dz2)
   FfnBatch fb;
   fb.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
+  const bool recompute = tiles >= ffn_fuse_min_tiles();   // weight gradients recompute dh: do not store it
   for (int i = 0; i < n; ++i) {
-    FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1t, p[i].w_2t, a[i].h, w[i].dh, drop_p);
+    FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1t, p[i].w_2t, a[i].h,
+                             recompute ? nullptr : w[i].dh, drop_p);
     GemmProb& q = f.epi;
     q.C = w[i].dz1; q.ldc = D;
     q.Z = (bf16*)a[i].z1; q.stats = a[i].st1; q.gamma = p[i].g1;
@@ -249,17 +253,32 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
 
 // ---- encoder layer backward, off the critical path: every parameter gradient of the layer as ONE grouped
 // split-K launch (all groups x {linear2, linear1, out_proj, in_proj}); reads what the data phase left in w ----
-int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
-                                   float drop_p, void* stream_) {
-  if (n < 1 || n > MMST_MAX_GROUPS || !g || !a || !w) return MMST_ERR_ARG;
+int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                   const mmst_enc_bwd* w, float drop_p, void* stream_) {
+  if (n < 1 || n > MMST_MAX_GROUPS || !p || !g || !a || !w) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   GemmProb probs[4 * MMST_MAX_GROUPS];
-  int np = 0;
+  int np = 0, tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
+  const bool recompute = tiles >= ffn_fuse_min_tiles();   // must match mmst_encoder_layer_bwd_data
+  if (recompute) {
+    FfnWgradBatch wb;
+    wb.n = n;
+    for (int i = 0; i < n; ++i) {
+      FfnWgradProb& f = wb.p[i];
+      f.dZ = (const bf16*)w[i].dzd2; f.H = (const bf16*)a[i].h; f.X = (const bf16*)a[i].x1; f.W2T = (const bf16*)p[i].w_2t;
+      f.dW1 = g[i].w_1; f.db1 = g[i].b_1; f.dW2 = g[i].w_2; f.db2 = g[i].b_2;
+      f.M = a[i].B * a[i].S; f.drop_p = drop_p;
+    }
+    RUN(launch_ffn_wgrad(wb, st));
+  }
   for (int i = 0; i < n; ++i) {
     const int M = a[i].B * a[i].S;
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
-    probs[np++] = wgrad(w[i].dzd2, M, D, a[i].h, FF, g[i].w_2, g[i].b_2);
-    probs[np++] = wgrad(w[i].dh, M, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+    if (!recompute) {
+      probs[np++] = wgrad(w[i].dzd2, M, D, a[i].h, FF, g[i].w_2, g[i].b_2);
+      probs[np++] = wgrad(w[i].dh, M, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+    }
     probs[np++] = wgrad(dzd1, M, D, a[i].attn, D, g[i].w_o, g[i].b_o);
     probs[np++] = wgrad(w[i].dqkv, M, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
   }
@@ -269,7 +288,7 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_grads* g, const mmst_en
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                            const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
   RUN(mmst_encoder_layer_bwd_data(n, p, g, a, w, nhead, drop_p, seed, stream_));
-  return mmst_encoder_layer_bwd_weights(n, g, a, w, drop_p, stream_);
+  return mmst_encoder_layer_bwd_weights(n, p, g, a, w, drop_p, stream_);
 }
 
 int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,

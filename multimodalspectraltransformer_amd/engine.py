@@ -683,7 +683,7 @@ class Engine:
                                                     C.c_uint32(self.layer_seed(32 + l)), st),
                     "mmst_encoder_layer_bwd_data")
             weights_after_data()
-            L.check(lib.mmst_encoder_layer_bwd_weights(1, pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
+            L.check(lib.mmst_encoder_layer_bwd_weights(1, pl.cross_p[l], pl.cross_g[l], pl.cross_a[l], pl.cross_w[l],
                                                        C.c_float(p_drop), wst), "mmst_encoder_layer_bwd_weights")
         if on_segment:
             on_segment("cross")
@@ -707,7 +707,8 @@ class Engine:
                                                     C.c_uint32(self.layer_seed(l)), st),
                     "mmst_encoder_layer_bwd_data")
             weights_after_data()
-            L.check(lib.mmst_encoder_layer_bwd_weights(pl.n_groups, pl.modal_g[l], pl.modal_a[l], pl.modal_w[l],
+            L.check(lib.mmst_encoder_layer_bwd_weights(pl.n_groups, pl.modal_p[l], pl.modal_g[l], pl.modal_a[l],
+                                                       pl.modal_w[l],
                                                        C.c_float(p_drop), wst), "mmst_encoder_layer_bwd_weights")
         # embeddings
         G_, s, keep = pl.embed_structs

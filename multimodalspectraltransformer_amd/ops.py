@@ -91,6 +91,16 @@ def ffn_launch(batch, backward=False):
     L.check(L.lib().mmst_ffn(C.byref(batch), int(backward), L.stream_ptr()), "mmst_ffn")
 
 
+def ffn_wgrad(groups):
+    """groups: list of dicts with FfnWgradProb fields (tensors for pointers)."""
+    b = L.FfnWgradBatch()
+    b.n = len(groups)
+    for i, g in enumerate(groups):
+        for k, v in g.items():
+            setattr(b.p[i], k, L.ptr(v) if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().mmst_ffn_wgrad(C.byref(b), L.stream_ptr()), "mmst_ffn_wgrad")
+
+
 def eptr(t, offset_elems):
     """Device address of element `offset_elems` of tensor t."""
     return t.data_ptr() + offset_elems * t.element_size()

@@ -270,6 +270,31 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
         L.check(L.lib().mmst_ffn_config(-1), "cfg")
 
 
+@pytest.mark.parametrize("M,groups,p", [(1024, 1, 0.0), (1000, 2, 0.1), (77, 1, 0.1), (8256, 1, 0.1)])
+def test_ffn_wgrad_recompute(M, groups, p):
+    """dW1/db1/dW2/db2 of the feed-forward block from (dz, h, x, W2^T) with dh recomputed in the kernel,
+    accumulated on top of existing gradient content, against fp32 torch math."""
+    gs, keep = [], []
+    for gi in range(groups):
+        Mg, sd = M + 40 * gi, 20 * gi
+        dz, x = bf(rnd(Mg, 128, seed=sd + 1)), bf(rnd(Mg, 128, seed=sd + 2))
+        h = bf(torch.relu(rnd(Mg, 2048, seed=sd + 3)))
+        w2 = bf(rnd(128, 2048, scale=0.05, seed=sd + 4))
+        dW1, db1 = rnd(2048, 128, seed=sd + 5), rnd(2048, seed=sd + 6)
+        dW2, db2 = rnd(128, 2048, seed=sd + 7), rnd(128, seed=sd + 8)
+        init = [t.clone() for t in (dW1, db1, dW2, db2)]
+        gs.append(dict(dZ=dz, H=h, X=x, W2T=w2.t().contiguous(), dW1=dW1, db1=db1, dW2=dW2, db2=db2, M=Mg, drop_p=p))
+        keep.append((dz, x, h, w2, dW1, db1, dW2, db2, init))
+    ops.ffn_wgrad(gs)
+    torch.cuda.synchronize()
+    for dz, x, h, w2, dW1, db1, dW2, db2, init in keep:
+        dh = bf((dz.float() @ w2.float()) * (h.float() > 0) / (1 - p)).float()
+        close(dW2 - init[2], dz.float().t() @ h.float(), rtol=5e-3, atol=5e-3)
+        close(db2 - init[3], dz.float().sum(0), rtol=5e-3, atol=5e-3)
+        close(dW1 - init[0], dh.t() @ x.float(), rtol=5e-3, atol=5e-3)
+        close(db1 - init[1], dh.sum(0), rtol=5e-3, atol=5e-3)
+
+
 def test_transpose_bf16():
     import ctypes as C
     src = bf(rnd(3 * 2048 * 128 + 64, seed=5))
