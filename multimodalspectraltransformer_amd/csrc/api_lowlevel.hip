@@ -46,6 +46,11 @@ int mmst_ffn_config(int fuse_min_tiles) {
   ffn_set_fuse_min_tiles(fuse_min_tiles);
   return MMST_OK;
 }
+// 1: feed-forward weight gradients of fused launches recompute the hidden gradient; 0: they read a stored one
+int mmst_ffn_wgrad_config(int recompute) {
+  ffn_set_wgrad_recompute(recompute ? 1 : 0);
+  return MMST_OK;
+}
 
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
 int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {

@@ -53,3 +53,5 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream);
 // (default 96, or the environment variable MMST_FFN_FUSE_MIN_TILES; negative restores the default).
 void ffn_set_fuse_min_tiles(int tiles);
 int ffn_fuse_min_tiles();
+int ffn_wgrad_recompute();          // see ffn.hip
+void ffn_set_wgrad_recompute(int on);

@@ -546,5 +546,17 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   return MMST_OK;
 }
 
+// Weight gradients of fused launches: 0 = the backward kernel stores the hidden gradient and the grouped split-K
+// GEMM consumes it (default: measured slightly faster inside a training step), 1 = ffn_wgrad.hip recomputes it
+// (no [rows][2048] gradient buffer is written or read).  Environment: MMST_FFN_WGRAD_RECOMPUTE.
+int g_wgrad_recompute = -1;
+int ffn_wgrad_recompute() {
+  if (g_wgrad_recompute < 0) {
+    const char* e = getenv("MMST_FFN_WGRAD_RECOMPUTE");
+    g_wgrad_recompute = (e && atoi(e) > 0) ? 1 : 0;
+  }
+  return g_wgrad_recompute;
+}
+void ffn_set_wgrad_recompute(int on) { g_wgrad_recompute = on; }
 void ffn_set_fuse_min_tiles(int tiles) { g_fuse_min_tiles = tiles; }
 int ffn_fuse_min_tiles() { return fuse_min_tiles(); }

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int DM = 128, FF = 2048, JC = 128, NJ = FF / JC, RS = 16, STEP = 32;
+constexpr int NBUF = 3;
 constexpr int IMG = STEP * 256;   // one 32-row x 128-column bf16 tile, rows of 256 B
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -28,9 +29,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ int img_off(int r, int ch) { return r * 256 + (((((ch >> 1) ^ fsw(r)) << 1) | (ch & 1)) << 4); }
 
 __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch batch) {
-  // [2 buffers][dz | h | x images] then the dh image; reused as the atomic staging area at the end
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * IMG + IMG];
-  unsigned char* dhimg = smem + 6 * IMG;
+  // [3 buffers][dz | h | x images] then the dh image (reused as the atomic staging area at the end): 80 KiB.
+  // The launch adds 2 KiB of unused dynamic LDS so that at most ONE workgroup of this kernel fits a CU, while the
+  // register budget stays that of two waves per SIMD: the launches of the activation-gradient stream this kernel
+  // runs beside always find LDS and registers on every CU.
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * 3 * IMG + IMG];
+  unsigned char* dhimg = smem + NBUF * 3 * IMG;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = NJ * RS;
@@ -195,14 +199,18 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
 
   const int s1f = (s1 * STEP <= M) ? s1 : s1 - 1;   // steps [s0, s1f) are full; at most one ragged step follows
   if (s0 < s1f) stage(s0, 0);
+  if (s0 + 1 < s1f) stage(s0 + 1, 1);
+  int b = 0;
   for (int s = s0; s < s1f; ++s) {
-    const int b = (s - s0) & 1;
-    // tiles of this step have landed (own portions: vmcnt; everyone's: barrier); the other buffer and the dh
-    // image are free again (all waves are past the previous step's reads)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // Tiles of this step have landed: own portions once only the 6 DMA instructions of the next step are still
+    // outstanding, everyone's after the barrier, which also frees the buffer of step s-1 and the dh image.
+    if (s + 1 < s1f) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 1 < s1f) stage(s + 1, b ^ 1);
+    const int b2 = b == 0 ? 2 : b - 1;                // (b + 2) % 3
+    if (s + 2 < s1f) stage(s + 2, b2);
     step(b);
+    b = b == NBUF - 1 ? 0 : b + 1;
   }
   if (s1f < s1) {
     __syncthreads();
@@ -258,7 +266,7 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
     const FfnWgradProb& p = b.p[i];
     if (p.M < 1 || !p.dZ || !p.H || !p.X || !p.W2T || !p.dW1 || !p.db1 || !p.dW2 || !p.db2) return MMST_ERR_ARG;
   }
-  hipLaunchKernelGGL(ffn_wgrad_kernel, dim3(b.n * NJ * RS), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(ffn_wgrad_kernel, dim3(b.n * NJ * RS), dim3(256), 2048, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

@@ -197,7 +197,7 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
   fb.n = n;
   int tiles = 0;
   for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
-  const bool recompute = tiles >= ffn_fuse_min_tiles();   // weight gradients recompute dh: do not store it
+  const bool recompute = ffn_wgrad_recompute() && tiles >= ffn_fuse_min_tiles();   // then dh is not stored
   for (int i = 0; i < n; ++i) {
     FfnProb f = ffn_bwd_prob(w[i].dzd2, w[i].dz2, a[i].B * a[i].S, p[i].w_1t, p[i].w_2t, a[i].h,
                              recompute ? nullptr : w[i].dh, drop_p);
@@ -260,7 +260,7 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_e
   GemmProb probs[4 * MMST_MAX_GROUPS];
   int np = 0, tiles = 0;
   for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
-  const bool recompute = tiles >= ffn_fuse_min_tiles();   // must match mmst_encoder_layer_bwd_data
+  const bool recompute = ffn_wgrad_recompute() && tiles >= ffn_fuse_min_tiles();   // as in mmst_encoder_layer_bwd_data
   if (recompute) {
     FfnWgradBatch wb;
     wb.n = n;
