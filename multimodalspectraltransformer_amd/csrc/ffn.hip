@@ -433,31 +433,37 @@ int prepare(FfnBatch& b, bool bwd) {
   return total;
 }
 
-// second stage of a hidden-split launch: sum the fp32 slabs of a 128-row tile and run the row epilogue
+// second stage of a hidden-split launch: one wave per 32 rows sums the fp32 slabs and runs the row epilogue
+// (few rows by construction, so the finest decomposition the row-owning layout allows)
 template <bool BWD>
-__global__ __launch_bounds__(256) void ffn_rows_kernel(const FfnBatch batch) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4096];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int g = 0, first = 0;
+__global__ __launch_bounds__(64) void ffn_rows_kernel(const FfnBatch batch) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[1024];
+  const int lane = threadIdx.x;
+  int g = 0, first = 0, acc_blocks = 0;
 #pragma unroll
-  for (int i = 1; i < FFN_MAX_GROUPS; ++i)
-    if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin / batch.p[i].hsplit) { g = i; first = batch.p[i].tile_begin / batch.p[i].hsplit; }
+  for (int i = 0; i < FFN_MAX_GROUPS; ++i) {
+    if (i < batch.n) {
+      if (i > 0 && (int)blockIdx.x >= acc_blocks) { g = i; first = acc_blocks; }
+      acc_blocks += (batch.p[i].epi.Pn + 31) / 32;
+    }
+  }
   const FfnProb& pr = batch.p[g];
-  const int M = pr.epi.Pn, p0 = ((int)blockIdx.x - first) * BP, pw0 = wave * 32;
+  const int M = pr.epi.Pn, p0 = ((int)blockIdx.x - first) * 32;
   f32x4 acc[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  add_slabs(acc, pr.ws, pr.hsplit, M, p0, pw0, lane);
-  if (BWD) epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
-  else epi_ln(acc, pr.epi, p0, pw0, lane);
+  add_slabs(acc, pr.ws, pr.hsplit, M, p0, 0, lane);
+  if (BWD) epi_lnbwd<1>(acc, pr.epi, p0, 0, lane, 0, lane, smem);
+  else epi_ln(acc, pr.epi, p0, 0, lane);
 }
 
-int row_epilogue(const FfnBatch& b, bool bwd, int split_total, hipStream_t stream) {
-  const int tiles = split_total / b.p[0].hsplit;   // every group uses the same split
-  if (bwd) hipLaunchKernelGGL((ffn_rows_kernel<true>), dim3(tiles), dim3(256), 0, stream, b);
-  else hipLaunchKernelGGL((ffn_rows_kernel<false>), dim3(tiles), dim3(256), 0, stream, b);
+int row_epilogue(const FfnBatch& b, bool bwd, hipStream_t stream) {
+  int blocks = 0;
+  for (int i = 0; i < b.n; ++i) blocks += (b.p[i].epi.Pn + 31) / 32;
+  if (bwd) hipLaunchKernelGGL((ffn_rows_kernel<true>), dim3(blocks), dim3(64), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_rows_kernel<false>), dim3(blocks), dim3(64), 0, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
@@ -530,7 +536,7 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
   else hipLaunchKernelGGL((ffn_fwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
-  if (split) return row_epilogue(b, false, total, stream);
+  if (split) return row_epilogue(b, false, stream);
   return MMST_OK;
 }
 
@@ -542,7 +548,7 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   if (split) hipLaunchKernelGGL((ffn_bwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
   else hipLaunchKernelGGL((ffn_bwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
-  if (split) return row_epilogue(b, true, total, stream);
+  if (split) return row_epilogue(b, true, stream);
   return MMST_OK;
 }
 

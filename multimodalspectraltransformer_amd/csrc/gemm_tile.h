@@ -236,6 +236,8 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[2][8], const GemmProb& pr, i
 
 // ---- LayerNorm backward on the same layout: dy = acc + R; C = dz, C2 = drop(dz); dgamma/dbeta column sums
 // (in-wave shuffles, then the 4 waves through `smem`, >= 4 KiB, which must be free of live data).
+// NW = waves of the workgroup (4: 128-row tile, 1: a single wave with its 32 rows).
+template <int NW = 4>
 __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[2][8], const GemmProb& pr, int p0, int pw0, int lane, int wave,
                                           int tid, unsigned char* smem) {
   constexpr int MT = 2;
@@ -312,7 +314,7 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[2][8], const GemmProb& pr
       }
     }
   }
-  // column sums over the tile's 128 rows: 16 lanes (lane&15) in-wave, then 4 waves via LDS
+  // column sums over the tile's rows: 16 lanes (lane&15) in-wave, then the NW waves via LDS
   if (pr.dgamma) {
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp)
@@ -336,10 +338,11 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[2][8], const GemmProb& pr
         }
     }
     __syncthreads();
-    {
-      int which = tid >> 7, col = tid & 127;
-      float s = red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col] +
-                red[(2 * 2 + which) * 128 + col] + red[(3 * 2 + which) * 128 + col];
+    for (int o = tid; o < 256; o += NW * 64) {
+      int which = o >> 7, col = o & 127;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * 128 + col];
       atomicAdd((which ? pr.dbeta : pr.dgamma) + col, s);
     }
   }
