@@ -433,12 +433,14 @@ int prepare(FfnBatch& b, bool bwd) {
   return total;
 }
 
-// second stage of a hidden-split launch: one wave per 32 rows sums the fp32 slabs and runs the row epilogue
-// (few rows by construction, so the finest decomposition the row-owning layout allows)
+// Second stage of a hidden-split launch, 32 rows per workgroup.  Few rows by construction, so the kernel is
+// built around memory latency, not throughput: its 4 waves each fetch a quarter of the fp32 slabs in ONE round of
+// independent loads, three of them hand their partial sums over through LDS and end, and the first wave (the
+// layout in which a wave owns whole rows) adds them and runs the row epilogue.
 template <bool BWD>
-__global__ __launch_bounds__(64) void ffn_rows_kernel(const FfnBatch batch) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[1024];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void ffn_rows_kernel(const FfnBatch batch) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16 * 64 * 16];   // 3 partial accumulators, 48 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0, first = 0, acc_blocks = 0;
 #pragma unroll
   for (int i = 0; i < FFN_MAX_GROUPS; ++i) {
@@ -454,7 +456,22 @@ __global__ __launch_bounds__(64) void ffn_rows_kernel(const FfnBatch batch) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  add_slabs(acc, pr.ws, pr.hsplit, M, p0, 0, lane);
+  add_slabs<FFN_MAX_HSPLIT / 4>(acc, pr.ws, wave, 4, pr.hsplit, M, p0, 0, lane);
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[((wave - 1) * 16 + i * 8 + j) * 64 + lane] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] += part[(w * 16 + i * 8 + j) * 64 + lane];
   if (BWD) epi_lnbwd<1>(acc, pr.epi, p0, 0, lane, 0, lane, smem);
   else epi_ln(acc, pr.epi, p0, 0, lane);
 }
@@ -462,8 +479,8 @@ __global__ __launch_bounds__(64) void ffn_rows_kernel(const FfnBatch batch) {
 int row_epilogue(const FfnBatch& b, bool bwd, hipStream_t stream) {
   int blocks = 0;
   for (int i = 0; i < b.n; ++i) blocks += (b.p[i].epi.Pn + 31) / 32;
-  if (bwd) hipLaunchKernelGGL((ffn_rows_kernel<true>), dim3(blocks), dim3(64), 0, stream, b);
-  else hipLaunchKernelGGL((ffn_rows_kernel<false>), dim3(blocks), dim3(64), 0, stream, b);
+  if (bwd) hipLaunchKernelGGL((ffn_rows_kernel<true>), dim3(blocks), dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_rows_kernel<false>), dim3(blocks), dim3(256), 0, stream, b);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

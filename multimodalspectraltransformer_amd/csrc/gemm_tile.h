@@ -142,25 +142,24 @@ __device__ __forceinline__ void store_slab(const f32x4 (&acc)[2][8], float* slab
     }
   }
 }
-__device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs, int n, int rows, int p0, int pw0, int lane) {
+// acc += slabs s0, s0 + stride, ... (< n) for the 32 rows at p0 + pw0; all loads of a call are independent
+template <int MAXS>
+__device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs, int s0, int stride, int n, int rows,
+                                          int p0, int pw0, int lane) {
   const int q = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
     if (m >= rows) continue;
 #pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-      // all slabs of this 8-column piece in flight at once (n <= 8), then summed
-      f32x4 lo[8], hi[8];
+    for (int k = 0; k < MAXS; ++k) {
+      const int s = s0 + k * stride;
+      if (s >= n) continue;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const float* d = slabs + ((size_t)(s < n ? s : 0) * rows + m) * 128 + tp * 32 + 8 * q;
-        lo[s] = *reinterpret_cast<const f32x4*>(d);
-        hi[s] = *reinterpret_cast<const f32x4*>(d + 4);
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        if (s < n) { acc[mt][2 * tp] += lo[s]; acc[mt][2 * tp + 1] += hi[s]; }
+      for (int tp = 0; tp < 4; ++tp) {
+        const float* d = slabs + ((size_t)s * rows + m) * 128 + tp * 32 + 8 * q;
+        acc[mt][2 * tp] += *reinterpret_cast<const f32x4*>(d);
+        acc[mt][2 * tp + 1] += *reinterpret_cast<const f32x4*>(d + 4);
       }
     }
   }
