@@ -144,12 +144,16 @@ __device__ __forceinline__ BlockCoord locate(const AttnBatch& batch) {
   for (int i = 1; i < ATTN_MAX_GROUPS; ++i)
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].block_begin) g = i;
   const AttnProb& pr = batch.p[g];
+  // Block index major, (batch, head group) minor: the partly filled last block of every sequence is dispatched
+  // last (a short final round instead of a full one), and the blocks that share one (batch, head group)'s K/V are
+  // B * ngroups ids apart, i.e. on one XCD's L2 whenever that is a multiple of 8.
   int local = blockIdx.x - pr.block_begin;
-  int bg = local / pr.blocks_per_bh;
   const int ngroups = pr.H / Cfg<HD>::HG;
+  const int nbg = pr.B * ngroups;
+  const int bg = local % nbg;
   BlockCoord c;
   c.g = g;
-  c.blk = local % pr.blocks_per_bh;
+  c.blk = local / nbg;
   c.b = bg / ngroups;
   c.hg = bg % ngroups;
   return c;
