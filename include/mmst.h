@@ -116,6 +116,25 @@ typedef struct {
                     hidden dimension over up to 8 workgroups per row tile (NULL: no split) */
 } mmst_dec_acts;
 
+/* ---- one decoder layer for ONE new target position with cached keys/values (inference) ----
+ * The reference's decode loops (validate_generate_MMT_v15_4.py:744-766, models_MMT_v15_4.py:1238-1262) re-run the
+ * decoder on the whole prefix for every token; rows of earlier positions do not change under the causal mask, so
+ * this entry point computes only the row of position `pos`: its Q|K|V projection is appended to qkv_cache, self-
+ * attention reads keys/values 0..pos from the cache, cross-attention reads kvc (projected once per sequence).
+ * Same arithmetic per row as mmst_decoder_layer_fwd without dropout. */
+typedef struct {
+  const void* x; void* y;      /* [B][128] input / output row of this position */
+  void* qkv_cache;             /* [B][cap][384] Q|K|V rows of positions 0..pos (row pos is written by the call) */
+  const void* kvc;             /* [B*L][256] cross-attention K|V of the encoder memory */
+  const float* mem_bias;       /* [B][L] additive key bias, or NULL */
+  void* attn; void* x1; void* qc; void* x2;   /* scratch, [B][128] each */
+  void* h;                     /* scratch [B][2048] */
+  float* lse;                  /* scratch [B][16] */
+  float* ffn_ws;               /* optional fp32 [8][B][128], see mmst_dec_acts.ffn_ws */
+  int B, pos, cap, L;
+} mmst_dec_step;
+int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, int nhead, void* stream);
+
 typedef struct {
   const void* dz3; const void* dzd3;
   void* dh; void* dz2; void* dzd2; void* da; void* dqc; void* dkvc; void* dz1; void* dzd1; void* dqkv; float* delta;

@@ -45,7 +45,7 @@ class AttnProb(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
         ("lddo", C.c_int), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Sk", C.c_int),
-        ("seed", C.c_uint32), ("block_begin", C.c_int), ("blocks_per_bh", C.c_int),
+        ("seed", C.c_uint32), ("block_begin", C.c_int), ("blocks_per_bh", C.c_int), ("kv_rows", C.c_int),
     ]
 
 
@@ -151,6 +151,11 @@ class DecActs(C.Structure):
     _fields_ = _ptrs("x", "y", "mem", "mem_bias", "qkv", "attn1", "lse1", "z1", "st1", "x1", "qc", "kvc", "attn2",
                      "lse2", "z2", "st2", "x2", "h", "z3", "st3") + [
         ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int), ("ffn_ws", C.c_void_p)]
+
+
+class DecStep(C.Structure):
+    _fields_ = _ptrs("x", "y", "qkv_cache", "kvc", "mem_bias", "attn", "x1", "qc", "x2", "h", "lse", "ffn_ws") + [
+        ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int)]
 
 
 class DecBwd(C.Structure):

@@ -20,6 +20,8 @@ struct AttnProb {
   uint32_t seed;
   int block_begin;     // filled by the launcher
   int blocks_per_bh;   // filled by the launcher
+  int kv_rows;         // forward only: rows per batch element of the K/V buffers (0 = Sk); > Sk for a K/V
+                       // cache that has room for more positions than are attended to
 };
 
 #define ATTN_MAX_GROUPS 6

@@ -213,8 +213,9 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   for (int c0 = 0; c0 < Sk; c0 += KC) {
     const int nvalid = min(KC, Sk - c0);
     __syncthreads();
-    const bf16* ksrc = pr.K + (size_t)(b * Sk + c0) * pr.ldk + gcol;
-    const bf16* vsrc = pr.V + (size_t)(b * Sk + c0) * pr.ldv + gcol;
+    const int kvr = (!BWD && pr.kv_rows > 0) ? pr.kv_rows : Sk;
+    const bf16* ksrc = pr.K + ((size_t)b * kvr + c0) * pr.ldk + gcol;
+    const bf16* vsrc = pr.V + ((size_t)b * kvr + c0) * pr.ldv + gcol;
     if (!BWD) {
       stage<true, false>(Kimg, nullptr, ksrc, pr.ldk, nvalid, tid, nthr);
       stage<false, true>(nullptr, Timg, vsrc, pr.ldv, nvalid, tid, nthr);

@@ -375,6 +375,72 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
   return MMST_OK;
 }
 
+// ---- decoder layer, one new position with cached keys/values ----
+int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, int nhead, void* stream_) {
+  if (!p || !s || nhead != 16 || s->B < 1 || s->pos < 0 || s->pos >= s->cap || s->L < 1) return MMST_ERR_ARG;
+  if (!s->x || !s->y || !s->qkv_cache || !s->kvc || !s->attn || !s->x1 || !s->qc || !s->x2 || !s->h || !s->lse)
+    return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  const int hd = D / nhead, B = s->B;
+  GemmBatch gb;
+  AttnBatch ab;
+  gb.n = 1;
+  // Q|K|V of the new row, straight into its cache slot (row b*cap + pos)
+  {
+    GemmProb g = fwd_linear(s->x, B, D, p->w_qkv, 3 * D, p->b_qkv, s->qkv_cache);
+    g.cS = 1; g.cL = s->cap; g.coff = s->pos;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  // self-attention of the new row over positions 0..pos (every cached key is visible: no mask needed)
+  memset(&ab, 0, sizeof(ab));
+  ab.n = 1; ab.hd = hd; ab.causal = 0; ab.drop_p = 0.f;
+  {
+    AttnProb& q = ab.p[0];
+    const bf16* cache = (const bf16*)s->qkv_cache;
+    q.Q = cache + (size_t)s->pos * 3 * D; q.ldq = s->cap * 3 * D;   // one query row per batch element
+    q.K = cache + D; q.V = cache + 2 * D; q.ldk = q.ldv = 3 * D; q.kv_rows = s->cap;
+    q.O = (bf16*)s->attn; q.ldo = D; q.lse = s->lse;
+    q.B = B; q.H = nhead; q.Tq = 1; q.Sk = s->pos + 1;
+  }
+  RUN(launch_attn_fwd(ab, st));
+  {
+    GemmProb g = fwd_linear(s->attn, B, D, p->w_o, D, p->b_o, s->x1);
+    g.R = (const bf16*)s->x; g.ldr = D; g.gamma = p->g1; g.beta = p->be1;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  // cross-attention: query from the new row, keys/values of the memory projected once per sequence
+  gb.p[0] = fwd_linear(s->x1, B, D, p->w_cqkv, D, p->b_cqkv, s->qc);
+  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  {
+    AttnProb& q = ab.p[0];
+    memset(&q, 0, sizeof(q));
+    const bf16* kv = (const bf16*)s->kvc;
+    q.Q = (const bf16*)s->qc; q.ldq = D;
+    q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
+    q.kbias = s->mem_bias;
+    q.O = (bf16*)s->attn; q.ldo = D; q.lse = s->lse;
+    q.B = B; q.H = nhead; q.Tq = 1; q.Sk = s->L;
+  }
+  RUN(launch_attn_fwd(ab, st));
+  {
+    GemmProb g = fwd_linear(s->attn, B, D, p->w_co, D, p->b_co, s->x2);
+    g.R = (const bf16*)s->x1; g.ldr = D; g.gamma = p->g2; g.beta = p->be2;
+    gb.p[0] = g;
+  }
+  RUN(launch_gemm(gb, EPI_LN, false, false, st));
+  // feed-forward block + norm3
+  {
+    FfnBatch fb;
+    fb.n = 1;
+    fb.p[0] = ffn_fwd_prob(s->x2, B, p->w_1, p->b_1, p->w_2, p->b_2, p->g3, p->be3, s->h, nullptr, nullptr, s->y, 0.f, 0, 0);
+    fb.p[0].ws = s->ffn_ws;
+    RUN(launch_ffn_fwd(fb, st));
+  }
+  return MMST_OK;
+}
+
 // ---- decoder layer backward, critical path ----
 int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
                                 const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {

@@ -1,0 +1,31 @@
+"""Greedy-decode throughput of the full-size model (6+6 layers) on synthetic spectra: cached keys/values vs the
+reference's prefix re-run.  usage: bench_decode.py [batch] [max_len]"""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import mmt_oracle as O   # synthetic batch generator + config defaults only
+from multimodalspectraltransformer_amd import generate as gen
+from multimodalspectraltransformer_amd.models_MMT import MultimodalTransformer
+
+MODE = "1H_HSQC_COSY_IR_MF_MW"
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+cfg = O.default_cfg(training_mode=MODE)
+cfg.update(device="cuda:0", max_len=max(T, 128))
+config = argparse.Namespace(**cfg)
+torch.manual_seed(0)
+model = MultimodalTransformer(config, src_pad_idx=0).to("cuda:0").eval()
+batch = {k: v.cuda() for k, v in O.synthetic_batch(B, 5, MODE).items()}
+batch["src_HSQC_"], batch["src_COSY_"] = batch["src_HSQC"], batch["src_COSY"]
+with torch.no_grad():
+    gen.run_model(model, batch, config)
+    pl = model._last_plan
+    for cached in (True, False):
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks, probs = gen._decode_plan(model, pl, T, 1.0, 3, early_stop=False, cached=cached)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print("cached=%s: %d molecules x %d tokens in %.1f ms -> %.0f molecules/s, %.0f tokens/s" %
+              (cached, B, T, dt * 1e3, B / dt, B * T / dt), flush=True)
