@@ -78,10 +78,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MMST_BENCH_ONE_GPU=1 is a REHEARSAL of the multi-rank code path on a single-GPU box (all ranks share
+    # cuda:0 and reduce through gloo); its numbers mean nothing.  Real runs: one rank per GPU over RCCL.
+    rehearsal = os.environ.get("MMST_BENCH_ONE_GPU") == "1"
+    if rehearsal:
+        import faulthandler
+        local_rank = 0
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        faulthandler.dump_traceback_later(100, exit=True)   # a rehearsal that hangs says where
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from oracle import mmt_oracle as O   # synthetic batch generator + config defaults only
     from multimodalspectraltransformer_amd import _lib as L

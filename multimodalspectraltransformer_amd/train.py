@@ -27,40 +27,52 @@ def shard_indices(n, rank, world):
 
 
 class GradReducer:
-    """Average a flat gradient buffer over ranks in contiguous segments, each all-reduce launched on a
-    side stream as soon as its segment is final (device tensors: RCCL; CPU tensors: gloo)."""
+    """Average a flat gradient buffer over ranks in contiguous segments, each all-reduce issued as soon as its
+    segment is final (device tensors: RCCL; CPU tensors: gloo).
+
+    Device tensors: the collective is issued asynchronously with the engine's weight-gradient stream current.
+    torch's process group runs it on its own communication stream, ordered after everything enqueued so far on
+    that stream (which by then has waited for the activation-gradient stream), so neither compute stream ever
+    waits for a reduction until finish().  No stream of its own is created: with four hardware queues per
+    process every extra stream shares a queue with a compute stream."""
 
     def __init__(self, flat, segments, world=None):
         self.flat, self.segments = flat, segments
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
         self.works = []
 
     def on_segment(self, name, also=()):
-        """`also`: further streams whose already-enqueued work writes this segment (the weight-gradient
-        stream of the engine)."""
+        """`also`: the engine's weight-gradient stream (its already-enqueued work writes this segment)."""
         if self.world == 1:
             return
         lo, hi = self.segments[name]
         view = self.flat[lo:hi]
-        if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            for s in also:
-                if s is not None:
-                    self.stream.wait_stream(s)
-            with torch.cuda.stream(self.stream):
+        side = next((s for s in also if s is not None), None) if self.cuda else None
+        if self.cuda and dist.get_backend() == "gloo":
+            # single-GPU rehearsal of the multi-rank path (several ranks on one card): stage through the host,
+            # synchronously -- this exercises the segment bookkeeping, not the overlap
+            if side is not None:
+                side.synchronize()
+            torch.cuda.current_stream().synchronize()
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            view.copy_(host)
+        elif side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
-        """Wait for the segment reductions; the caller scales by 1/world (fused into the optimizer)."""
-        for w in self.works:
+        """Wait for the segment reductions (device tensors: the current stream waits, not the host); the caller
+        scales by 1/world (fused into the optimizer)."""
+        for i, w in enumerate(self.works):
+            if os.environ.get("MMST_DEBUG_REDUCE"):
+                print(f"[reduce] rank {dist.get_rank()} waits for segment work {i} of {len(self.works)}", flush=True)
             w.wait()
         self.works = []
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
         return 1.0 / self.world
 
 

@@ -34,3 +34,19 @@ for M in Ms:
         for _ in range(20): ops.ffn_launch(b, bwd)
         e1.record(); torch.cuda.synchronize()
         print("M=%d %s %.1f us" % (M, name, e0.elapsed_time(e1) * 1000 / 20), flush=True)
+    # weight gradients: recomputing kernel vs two split-K GEMMs on a stored hidden gradient
+    dW1 = torch.zeros(2048, 128, device=dev); db1 = torch.zeros(2048, device=dev)
+    dW2 = torch.zeros(128, 2048, device=dev); db2 = torch.zeros(128, device=dev)
+    wg = [dict(dZ=dzd, H=h, X=x, W2T=w2t, dW1=dW1, db1=db1, dW2=dW2, db2=db2, M=M, drop_p=0.1)]
+    ks = max(1, min(64, 128 // 16))
+    gg = [dict(P=dzd, Q=h, C=dW2, dbias=db2, ldp=128, ldq=2048, ldc=2048, Pn=128, Qn=2048, K=M, ksplit=ks),
+          dict(P=dh, Q=x, C=dW1, dbias=db1, ldp=2048, ldq=128, ldc=128, Pn=2048, Qn=128, K=M, ksplit=ks)]
+    for name, fn in (("wgrad recompute", lambda: ops.ffn_wgrad(wg)),
+                     ("wgrad stored dh", lambda: ops.gemm(gg, L.EPI_ATOMIC, pt=True, qt=True))):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        print("M=%d %s %.1f us" % (M, name, e0.elapsed_time(e1) * 1000 / 20), flush=True)
