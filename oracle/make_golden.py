@@ -7,7 +7,8 @@ only torch arithmetic of the reference is executed.  Weights are regenerated
 from a seed by oracle.mmt_oracle.make_state_dict and loaded into the reference
 module with load_state_dict, so the fixtures hold inputs and outputs only.
 
-    python oracle/make_golden.py
+    python oracle/make_golden.py          # everything
+    python oracle/make_golden.py data     # only tests/golden/dataloader.npz + tests/golden/csv/
 """
 import argparse
 import importlib.abc
@@ -212,10 +213,80 @@ def text_case(hf, dl):
     print('text ok', dec[:3])
 
 
+def data_case(dl):
+    """Item dictionaries of the reference's MultimodalData.__getitem__ on the first molecules of its own CSV
+    fixtures.  RDKit is absent, so the four RDKit results the method asks for (formula, exact mass, canonical
+    SMILES, fingerprint) are supplied from a sidecar computed from the SMILES strings; everything else (spectrum
+    parsing, normalisation, padding, blanking order, token framing, IR binning) is the reference's code."""
+    import csv
+    import random
+    import shutil
+    import pandas as pd
+    from multimodalspectraltransformer_amd import dataloaders as mine
+    src = f'{REF}/MMT_website/Runfolder/CSV_files'
+    files = {'1H': 'ML_NMR_1H_combined_ZINC_test_10x100.csv', '13C': 'ML_NMR_5M_XL_13C_test_10x100.csv',
+             'HSQC': 'ML_NMR_5M_XL_HSQC_test_10x100.csv', 'COSY': 'ML_NMR_5M_XL_COSY_test_10x100.csv'}
+    out_dir = os.path.join(ROOT, 'tests', 'golden', 'csv')
+    os.makedirs(out_dir, exist_ok=True)
+    rows = {m: {r[2]: r for r in csv.reader(open(f'{src}/{f}'))} for m, f in files.items()}
+    ids = [r[2] for r in list(csv.reader(open(f'{src}/{files["13C"]}')))[:6]]
+    # the longest 1H list of the file exercises truncation at 64 points
+    longest = max(rows['1H'], key=lambda k: rows['1H'][k][1].count('('))
+    if longest not in ids:
+        ids.append(longest)
+    for m in files:
+        with open(os.path.join(out_dir, f'{m}.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            for sid in ids:
+                w.writerow(rows[m][sid])
+    ir_src = f'{src}/website_real_example/real_IR/AZ10075521.csv'
+    shutil.copy(ir_src, os.path.join(out_dir, 'IR_example.csv'))
+    smiles = {sid: rows['13C'][sid][0] for sid in ids}
+    side_mf = {s: mine.mol_formula(s) for s in smiles.values()}
+    side_mw = {s: mine.exact_mol_weight(s) for s in smiles.values()}
+    dl.Chem.MolFromSmiles = lambda s: s
+    dl.Chem.MolToSmiles = lambda mol, canonical=True, isomericSmiles=True: mol
+    dl.rdMolDescriptors.CalcMolFormula = lambda mol: side_mf[mol]
+    dl.rdMolDescriptors.CalcExactMolWt = lambda mol: side_mw[mol]
+    dl.AllChem.GetMorganFingerprintAsBitVect = lambda mol, r, nBits=512: [0] * nBits
+    stoi = json.load(open(f'{REF}/stoi.json'))
+    stoi_MF = json.load(open(f'{REF}/stoi_MF.json'))
+    ds = dl.MultimodalData.__new__(dl.MultimodalData)
+    ds.stoi, ds.stoi_MF, ds.mode, ds.fingerprint_size = stoi, stoi_MF, 'all', 512
+    ds.possible_datasets = ["1H", "13C", "HSQC", "COSY", "IR"]
+    ds.ref_data = pd.DataFrame({'sample-id': ids})
+    ds.data_dict = {sid: {'1H': [rows['1H'][sid][1]], '13C': [rows['13C'][sid][1]], 'HSQC': [rows['HSQC'][sid][1]],
+                          'COSY': [rows['COSY'][sid][1]], 'IR': [], 'SMILES': smiles[sid]} for sid in ids}
+    out = {'ids': np.array(ids), 'formulas': np.array([side_mf[smiles[s]] for s in ids]),
+           'mw': np.array([side_mw[smiles[s]] for s in ids])}
+    cases = [('full', '1H_13C_HSQC_COSY_MF_MW', 0.0, 1), ('two', '1H_HSQC_MF_MW', 0.0, 2),
+             ('blank', '1H_13C_HSQC_COSY_IR_MF_MS_MW', 0.5, 3)]
+    for tag, mode, blank, seed in cases:
+        ds.config = argparse.Namespace(data_type='sgnn', training_mode=mode, padding_points_number=64, input_dim_1H=2,
+                                       input_dim_13C=1, input_dim_HSQC=2, input_dim_COSY=2, input_dim_IR=1000,
+                                       blank_percentage=blank, isomericSmiles=False, smi_randomizer=False,
+                                       IR_data_folder='/nonexistent', fingerprint_size=512)
+        random.seed(seed)
+        items = [ds[i] for i in range(len(ids))]
+        batch = dl.collate_fn(items)
+        for k, v in batch.items():
+            out[f'{tag}/{k}'] = np_(v)
+            out[f'{tag}/{k}/dtype'] = np.array(str(v.dtype))
+        out[f'{tag}/item0_dtypes'] = np.array(json.dumps({k: str(v.dtype) for k, v in items[0].items()}))
+    ds.config.IR_data_folder = os.path.dirname(ir_src)
+    ir, irm = ds._load_IR_data(ds.config, 'AZ10075521')
+    out['ir'], out['ir_mask'] = np_(ir), np_(irm)
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'dataloader.npz'), **out)
+    print('data ok', out['formulas'][:3], out['mw'][:3])
+
+
 def main():
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     M, vg, hf, dl = import_reference()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'data':      # only the data-path fixtures
+        data_case(dl)
+        return
     forward_case(M, 'fwd_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 3, seed=11, wseed=101, steps=2)
     forward_case(M, 'fwd_c1_L2', '1H', 2, 4, seed=12, wseed=102)
     forward_case(M, 'fwd_all_L1', '1H_13C_HSQC_COSY_IR_MF_MW', 1, 2, seed=13, wseed=103)
@@ -225,6 +296,7 @@ def main():
     greedy_case(M, vg, 'greedy_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 8, seed=21, wseed=201, gain=1.0)
     greedy_case(M, vg, 'greedy_c1_L2', '1H', 2, 4, seed=22, wseed=202, gain=1.0)
     text_case(hf, dl)
+    data_case(dl)
 
 
 if __name__ == '__main__':
