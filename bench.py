@@ -136,6 +136,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
     loss = float(out["loss"])
+    if rehearsal and world > 1:
+        # replicas that average their gradients every step stay bit-identical
+        ar = tm.model._engine.arena
+        sums = [None] * world
+        dist.all_gather_object(sums, [float(ar.P.double().sum()), float(ar.P.double().abs().sum())])
+        assert all(s == sums[0] for s in sums), f"replicas diverged: {sums}"
 
     if rank == 0:
         mols = world * args.batch * args.steps

@@ -40,7 +40,9 @@ class Arena:
                                           k.startswith("fp1.") or k.startswith("fc_out.") or
                                           k.startswith("real_data_linear."))]
         self.seg_embed_end_keys = len(order)
+        layer_first = {}            # index in `order` of the first parameter of each modality-encoder depth
         for l in range(nl):
+            layer_first[len(order)] = l
             for m in ALL_MODS:
                 order += [k for k in named if k.startswith(f"encoder_{m}.layers.{l}.")]
         mark_modal = len(order)
@@ -62,6 +64,8 @@ class Arena:
                 marks["decoder"] = off
             if i == self.seg_embed_end_keys:
                 marks["modal"] = off
+            if i in layer_first:
+                marks[f"modal_l{layer_first[i]}"] = off
             p = named[k]
             n = p.numel()
             slots = n
@@ -152,6 +156,18 @@ class Arena:
             if not skip:
                 out.append(k)
         return out
+
+    def reduce_segments(self):
+        """Gradient-reduction segments {name: (lo, hi)} in the order backward completes them: 'decoder' (decoder
+        layers + heads), 'cross', one per modality-encoder depth from the top ('modal_l5' ... 'modal_l0'), 'embed'."""
+        m = self.marks
+        nl = sum(1 for k in m if k.startswith("modal_l"))
+        segs = {"decoder": (m["decoder"], self.total), "cross": (m["cross"], m["decoder"])}
+        for l in reversed(range(nl)):
+            hi = m[f"modal_l{l + 1}"] if l + 1 < nl else m["cross"]
+            segs[f"modal_l{l}"] = (m[f"modal_l{l}"], hi)
+        segs["embed"] = (0, m["modal"])
+        return segs
 
     def active_ranges(self, mode):
         """Contiguous [lo, hi) element ranges of the flat buffers covering the active parameters."""
@@ -612,8 +628,9 @@ class Engine:
         Two streams: the critical path (activation gradients) runs on the current stream; each layer's
         parameter gradients (one grouped split-K launch) run on a second stream as soon as that layer's
         data phase is done, filling the CUs the small critical-path launches leave idle.
-        on_segment(name) is called when the launches that finish the gradient memory of 'decoder',
-        'cross', 'modal' have been ENQUEUED; self.wstream then holds the last of them."""
+        on_segment(name) is called when the launches that finish the gradient memory of a segment of
+        Arena.reduce_segments() ('decoder', 'cross', 'modal_l5' ... 'modal_l0', 'embed') have been ENQUEUED;
+        self.wstream then holds the last of them."""
         lib, ar, B, T, Lm = L.lib(), self.arena, pl.B, pl.T, pl.Lmem
         m = self.model
         nl, ndl = m.num_encoder_layers, m.num_decoder_layers
@@ -720,5 +737,5 @@ class Engine:
             ops.gemm([dict(P=_P(pl.ir_dpre), Q=_P(pl.ir_bf16), C=ar.g32(k + ".weight"), dbias=ar.g32(k + ".bias"),
                            ldp=D, ldq=1000, ldc=1000, Pn=D, Qn=1000, K=B, ksplit=1)], L.EPI_ATOMIC, pt=True, qt=True)
         if on_segment:
-            on_segment("modal")
+            on_segment("embed")
         main.wait_stream(ws)   # everything after backward (optimizer, readers of .grad) sees all gradients

@@ -36,8 +36,10 @@ class GradReducer:
     waits for a reduction until finish().  No stream of its own is created: with four hardware queues per
     process every extra stream shares a queue with a compute stream."""
 
-    def __init__(self, flat, segments, world=None):
-        self.flat, self.segments = flat, segments
+    def __init__(self, flat, segments, world=None, active=None):
+        """active: optional list of [lo, hi) ranges; only their intersection with a segment is reduced (parameters
+        outside never receive gradients in the current training mode, e.g. an absent modality's encoder)."""
+        self.flat, self.segments, self.active = flat, segments, active
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
         self.works = []
@@ -47,7 +49,14 @@ class GradReducer:
         if self.world == 1:
             return
         lo, hi = self.segments[name]
-        view = self.flat[lo:hi]
+        if self.active is None:
+            pieces = [(lo, hi)]
+        else:
+            pieces = [(max(lo, a), min(hi, b)) for a, b in self.active if max(lo, a) < min(hi, b)]
+        for a, b in pieces:
+            self._reduce(self.flat[a:b], also)
+
+    def _reduce(self, view, also):
         side = next((s for s in also if s is not None), None) if self.cuda else None
         if self.cuda and dist.get_backend() == "gloo":
             # single-GPU rehearsal of the multi-rank path (several ranks on one card): stage through the host,
@@ -168,9 +177,8 @@ class TransformerMultiGPU:
         eng.ensure(model._dev())
         ar = eng.arena
         if self.reducer is None or self.reducer.flat is not ar.G:
-            segs = {"decoder": (ar.marks["decoder"], ar.total), "cross": (ar.marks["cross"], ar.marks["decoder"]),
-                    "modal": (0, ar.marks["cross"])}
-            self.reducer = GradReducer(ar.G, segs, self.world)
+            self.reducer = GradReducer(ar.G, ar.reduce_segments(), self.world,
+                                       active=ar.active_ranges(self.config.training_mode))
         ar.G.zero_()
         loss = model.loss_and_backward(
             x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))

@@ -140,6 +140,18 @@ def test_arena_layout_segments_and_active_ranges():
     for k in ar.order:
         seg = covered[ar.offset[k]: ar.offset[k] + ar.numel[k]]
         assert seg.all() if k in act else not seg.any(), k
+    # reduction segments tile the whole buffer, in the order backward completes them, one per encoder depth
+    segs = ar.reduce_segments()
+    names = list(segs)
+    nl = model.num_encoder_layers
+    assert names == ["decoder", "cross"] + [f"modal_l{l}" for l in reversed(range(nl))] + ["embed"]
+    tiles = sorted(segs.values())
+    assert tiles[0][0] == 0 and tiles[-1][1] == ar.total and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+    for l in range(nl):
+        lo, hi = segs[f"modal_l{l}"]
+        inside = [k for k in ar.order if lo <= ar.offset[k] < hi]
+        assert inside and all(f".layers.{l}." in k and k.startswith("encoder_") and not k.startswith("encoder_cross")
+                              for k in inside)
     # load_state_dict writes through the views
     sd2 = O.make_state_dict(cfg, 4)
     model.load_state_dict(sd2)
@@ -215,6 +227,15 @@ scale = red.finish()
 want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
 assert torch.equal(flat, want), "all-reduce result wrong"
 assert abs(scale - 1.0 / world) < 1e-12
+# active ranges: only their intersection with a segment is reduced, the rest is left alone
+flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+red2 = GradReducer(flat2, segs, world, active=[(100, 450), (650, 900)])
+for name in ("decoder", "cross", "modal"):
+    red2.on_segment(name)
+red2.finish()
+i = torch.arange(n)
+act = ((i >= 100) & (i < 450)) | ((i >= 650) & (i < 900))
+assert torch.equal(flat2, torch.where(act, want, torch.arange(n, dtype=torch.float32) * (rank + 1)))
 # every molecule is seen exactly once per epoch across ranks (up to wrap-around padding)
 idx = shard_indices(37, rank, world)
 gathered = [None] * world
