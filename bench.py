@@ -139,9 +139,11 @@ def main():
     if rehearsal and world > 1:
         # replicas that average their gradients every step stay bit-identical
         ar = tm.model._engine.arena
+        mine = {k: float(ar.P[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
         sums = [None] * world
-        dist.all_gather_object(sums, [float(ar.P.double().sum()), float(ar.P.double().abs().sum())])
-        assert all(s == sums[0] for s in sums), f"replicas diverged: {sums}"
+        dist.all_gather_object(sums, mine)
+        bad = [k for k in ar.order if any(s[k] != sums[0][k] for s in sums)]
+        assert not bad, f"replicas diverged in {len(bad)} of {len(ar.order)} tensors, e.g. {bad[:6]}"
 
     if rank == 0:
         mols = world * args.batch * args.steps

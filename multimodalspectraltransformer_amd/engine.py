@@ -727,6 +727,10 @@ class Engine:
             L.check(lib.mmst_encoder_layer_bwd_weights(pl.n_groups, pl.modal_p[l], pl.modal_g[l], pl.modal_a[l],
                                                        pl.modal_w[l],
                                                        C.c_float(p_drop), wst), "mmst_encoder_layer_bwd_weights")
+            if on_segment:
+                # depth l is final: its norm2 gradients were written by the data pass of depth l+1 (or by the top
+                # LayerNorm backward), everything else by the two launches above
+                on_segment(f"modal_l{l}")
         # embeddings
         G_, s, keep = pl.embed_structs
         dx = (C.c_void_p * pl.n_groups)(*[_P(pl.dxseq[i]) for i in range(pl.n_groups)])

@@ -183,6 +183,17 @@ class TransformerMultiGPU:
         loss = model.loss_and_backward(
             x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))
         scale = self.reducer.finish()
+        if os.environ.get("MMST_DEBUG_REDUCE") and self.world > 1:
+            torch.cuda.synchronize()
+            mine = {k: float(ar.G[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
+            minep = {k: float(ar.P[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
+            allg, allp = [None] * self.world, [None] * self.world
+            dist.all_gather_object(allg, mine)
+            dist.all_gather_object(allp, minep)
+            badg = [k for k in ar.order if any(s[k] != allg[0][k] for s in allg)]
+            badp = [k for k in ar.order if any(s[k] != allp[0][k] for s in allp)]
+            print(f"[reduce] rank {dist.get_rank()} step {batch_idx}: {len(badg)} gradient tensors differ {badg[:3]}, "
+                  f"{len(badp)} parameter tensors differ before the update {badp[:3]}", flush=True)
         self.optimizer.step(self.config.training_mode, grad_scale=scale)
         out = {'loss': loss}
         if getattr(self.config, "gen_SMI_sequence", False):
