@@ -29,12 +29,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   unsigned char* Qimg = smem + BP * BK * 2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: consecutive workgroup ids rotate over the 8 XCDs (each with its own L2), so id % 8
+  // names the XCD.  Renumber so that each XCD works on a CONTIGUOUS run of logical tiles: tiles that share an
+  // operand (the Q-tiles of one row tile; the P-tiles of one split-K slice) are neighbours in logical order and
+  // now fetch that operand into one L2 instead of eight.  Bijective for any grid size.
+  int bid;
+  {
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < GEMM_MAX_GROUPS; ++i)
-    if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) g = i;
+    if (i < batch.n && bid >= batch.p[i].tile_begin) g = i;
   const GemmProb& pr = batch.p[g];
-  int local = blockIdx.x - pr.tile_begin;
+  int local = bid - pr.tile_begin;
   const int qt = local % pr.qtiles;
   local /= pr.qtiles;
   const int ptile = local % pr.ptiles;
