@@ -115,6 +115,16 @@ def test_state_dict_keys_and_shapes_match_reference():
     assert sum(p.numel() for p in full.parameters()) == 25566294
 
 
+def test_synthetic_workload_equals_oracle_generator():
+    """bench.py draws its batches from the package (the oracle is test infrastructure); both generators must stay
+    the same function of the seed so that the CPU baseline and the GPU run see the same workload."""
+    from multimodalspectraltransformer_amd import synthetic as S
+    for mode in ("1H_HSQC_COSY_IR_MF_MW", "1H_13C_HSQC_COSY_IR_MF_MS_MW"):
+        a, b = O.synthetic_batch(5, 7, mode), S.synthetic_batch(5, 7, mode)
+        assert sorted(a) == sorted(b) and all(torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype for k in a)
+    assert O.default_cfg() == S.default_config()
+
+
 def test_arena_layout_segments_and_active_ranges():
     from multimodalspectraltransformer_amd.engine import Arena
     model, cfg = _cpu_model()

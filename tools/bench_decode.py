@@ -3,14 +3,14 @@ reference's prefix re-run.  usage: bench_decode.py [batch] [max_len]"""
 import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from oracle import mmt_oracle as O   # synthetic batch generator + config defaults only
+from multimodalspectraltransformer_amd import synthetic as O
 from multimodalspectraltransformer_amd import generate as gen
 from multimodalspectraltransformer_amd.models_MMT import MultimodalTransformer
 
 MODE = "1H_HSQC_COSY_IR_MF_MW"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-cfg = O.default_cfg(training_mode=MODE)
+cfg = O.default_config(training_mode=MODE)
 cfg.update(device="cuda:0", max_len=max(T, 128))
 config = argparse.Namespace(**cfg)
 torch.manual_seed(0)
