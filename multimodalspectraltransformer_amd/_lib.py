@@ -45,7 +45,7 @@ class AttnProb(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
         ("lddo", C.c_int), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Sk", C.c_int),
-        ("seed", C.c_uint32), ("block_begin", C.c_int), ("blocks_per_bh", C.c_int), ("kv_rows", C.c_int),
+        ("seed", C.c_uint32), ("block_begin", C.c_int), ("blocks_per_bh", C.c_int), ("kv_rows", C.c_int), ("tail_o", C.c_int), ("tail_s", C.c_int),
     ]
 
 

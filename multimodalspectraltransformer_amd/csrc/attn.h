@@ -22,6 +22,7 @@ struct AttnProb {
   int blocks_per_bh;   // filled by the launcher
   int kv_rows;         // forward only: rows per batch element of the K/V buffers (0 = Sk); > Sk for a K/V
                        // cache that has room for more positions than are attended to
+  int tail_o, tail_s;  // filled by the launcher: owner / streamed rows handled outside the 32-row tiling
 };
 
 #define ATTN_MAX_GROUPS 6

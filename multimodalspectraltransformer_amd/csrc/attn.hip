@@ -20,6 +20,7 @@
 // Dropout on the attention probabilities is a counter hash of (b, h, q, key), so the
 // backward passes regenerate the forward's mask.
 #include "attn.h"
+#include <cstdlib>
 
 namespace {
 
@@ -59,6 +60,35 @@ __device__ __forceinline__ void stage(unsigned char* rm, unsigned char* tr, cons
     if (RM) *reinterpret_cast<uint4*>(rm + rm_off(row, ch)) = v;
     if (TR) {
       const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<unsigned short*>(tr + (ch * 8 + j) * TSTR + row * 2) = e[j];
+    }
+  }
+}
+
+// The same staging in two halves, so that the global loads of the NEXT chunk can be in flight while the current
+// chunk is being consumed (the q-owner kernels; a decoder cross-attention launch has one workgroup per CU and
+// nothing else to hide that latency behind).
+constexpr int NTHR = 64 * 8;
+constexpr int SLOTS = KC * (GC / 8) / NTHR;
+struct Staged { uint4 v[SLOTS]; };
+__device__ __forceinline__ void stage_load(Staged& st, const bf16* src, int ld, int nvalid, int tid) {
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int c = tid + i * NTHR, row = c / (GC / 8), ch = c % (GC / 8);
+    st.v[i] = make_uint4(0, 0, 0, 0);
+    if (row < nvalid) st.v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+  }
+}
+template <bool RM, bool TR>
+__device__ __forceinline__ void stage_store(const Staged& st, unsigned char* rm, unsigned char* tr, int tid) {
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int c = tid + i * NTHR, row = c / (GC / 8), ch = c % (GC / 8);
+    if (RM) *reinterpret_cast<uint4*>(rm + rm_off(row, ch)) = st.v[i];
+    if (TR) {
+      const unsigned short* e = reinterpret_cast<const unsigned short*>(&st.v[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         *reinterpret_cast<unsigned short*>(tr + (ch * 8 + j) * TSTR + row * 2) = e[j];
@@ -136,6 +166,138 @@ __device__ __forceinline__ void store_rows(bf16* rowptr, const f32x16& acc, floa
   }
 }
 
+__device__ __forceinline__ bf16x8 ldrow8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
+  return s;
+}
+__device__ __forceinline__ void store_row8(bf16* p, const float* v, float mul) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * mul);
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+// dropout keep flag of (query-row seed, key): the same hash the tile code evaluates pairwise
+__device__ __forceinline__ bool keep_of(uint32_t row_seed, int key, uint32_t thr) {
+  const uint32_t hb = attn_pair_bits(row_seed, (uint32_t)(key >> 1) * ATTN_PAIR_MUL);
+  return ((hb >> ((key & 1) * 16)) & 0xFFFFu) >= thr;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tail rows (head_dim 8, not causal).  The modality sequences are 129 (or 66) tokens long: 1 or 2 rows
+// beyond a multiple of 32 would cost a whole 32-row tile on either side of the score matrix (25 tiles instead
+// of 16 for 129 x 129).  Those rows never enter the MFMA tiling:
+//   * a tail row of the STREAMED side is folded in by every owner lane with plain FMAs (one score per lane);
+//   * a tail row of the OWNER side is computed by one wave with a lane per streamed row and wave reductions.
+// ------------------------------------------------------------------------------------------
+struct TailCtx {
+  float scale, scale2, dscale;
+  uint32_t thr;
+  bool dropping;
+};
+
+// forward (BWD = false: O row and lse) or dQ pass (BWD = true: dQ row and delta) of query row q of head hh
+template <bool BWD>
+__device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& tc, int b, int hh, int q, int lane) {
+  constexpr int HD = 8;
+  const int H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const int kvr = (!BWD && pr.kv_rows > 0) ? pr.kv_rows : Sk;
+  const size_t stat = (size_t)(b * H + hh) * Tq + q;
+  const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * Tq + q) * pr.ldq + hh * HD);
+  const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)stat);
+  const bf16* kbase = pr.K + (size_t)b * kvr * pr.ldk + hh * HD;
+  const bf16* vbase = pr.V + (size_t)b * kvr * pr.ldv + hh * HD;
+  float acc[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) acc[d] = 0.f;
+  if (!BWD) {
+    float m = NEG_BIG, l = 0.f;
+    for (int key = lane; key < Sk; key += 64) {
+      const bf16x8 kt = ldrow8(kbase + (size_t)key * pr.ldk), vt = ldrow8(vbase + (size_t)key * pr.ldv);
+      const float bt = pr.kbias ? pr.kbias[(size_t)b * Sk + key] * LOG2E : 0.f;
+      const float sc = dot8(qrow, kt) * tc.scale2 + bt;
+      const float mn = fmaxf(m, sc);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float p = __builtin_amdgcn_exp2f(sc - mn);
+      l = l * alpha + p;
+      m = mn;
+      if (tc.dropping) p = keep_of(rseed, key, tc.thr) ? p * tc.dscale : 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[d] = acc[d] * alpha + p * (float)vt[d];
+    }
+    const float M = wave_max(m);
+    const float f = __builtin_amdgcn_exp2f(m - M);
+    l = wave_sum(l * f);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] = wave_sum(acc[d] * f);
+    if (lane == 0) {
+      store_row8(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, acc, l > 0.f ? 1.0f / l : 0.f);
+      pr.lse[stat] = M + __builtin_amdgcn_logf(l);
+    }
+  } else {
+    const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * Tq + q) * pr.lddo + hh * HD);
+    const float delta = dot8(dorow, ldrow8(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD));
+    const float lse2 = pr.lse[stat];
+    for (int key = lane; key < Sk; key += 64) {
+      const bf16x8 kt = ldrow8(kbase + (size_t)key * pr.ldk), vt = ldrow8(vbase + (size_t)key * pr.ldv);
+      const float bt = pr.kbias ? pr.kbias[(size_t)b * Sk + key] * LOG2E : 0.f;
+      const float p = __builtin_amdgcn_exp2f(dot8(qrow, kt) * tc.scale2 + bt - lse2);
+      float dp = dot8(dorow, vt);
+      if (tc.dropping) dp = keep_of(rseed, key, tc.thr) ? dp * tc.dscale : 0.f;
+      const float ds = p * (dp - delta) * tc.scale;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[d] += ds * (float)kt[d];
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] = wave_sum(acc[d]);
+    if (lane == 0) {
+      store_row8(pr.dQ + (size_t)(b * Tq + q) * pr.lddq + hh * HD, acc, 1.0f);
+      pr.delta[stat] = delta;
+    }
+  }
+}
+
+// dK and dV rows of key `key` of head hh: a lane per query
+__device__ __forceinline__ void kv_owner_tail(const AttnProb& pr, const TailCtx& tc, int b, int hh, int key, int lane) {
+  constexpr int HD = 8;
+  const int H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  const bf16x8 kt = ldrow8(pr.K + (size_t)(b * Sk + key) * pr.ldk + hh * HD);
+  const bf16x8 vt = ldrow8(pr.V + (size_t)(b * Sk + key) * pr.ldv + hh * HD);
+  const float bt = pr.kbias ? pr.kbias[(size_t)b * Sk + key] * LOG2E : 0.f;
+  float dk[8], dv[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) dk[d] = dv[d] = 0.f;
+  for (int q = lane; q < Tq; q += 64) {
+    const size_t stat = (size_t)(b * H + hh) * Tq + q;
+    const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * Tq + q) * pr.ldq + hh * HD);
+    const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * Tq + q) * pr.lddo + hh * HD);
+    const float p = __builtin_amdgcn_exp2f(dot8(qrow, kt) * tc.scale2 + bt - pr.lse[stat]);
+    float dp = dot8(dorow, vt), pk = p;
+    if (tc.dropping) {
+      const bool keep = keep_of(attn_row_seed(pr.seed, (uint32_t)stat), key, tc.thr);
+      dp = keep ? dp * tc.dscale : 0.f;
+      pk = keep ? p * tc.dscale : 0.f;
+    }
+    const float ds = p * (dp - pr.delta[stat]) * tc.scale;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dv[d] += pk * (float)dorow[d];
+      dk[d] += ds * (float)qrow[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    dk[d] = wave_sum(dk[d]);
+    dv[d] = wave_sum(dv[d]);
+  }
+  if (lane == 0) {
+    store_row8(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dk, 1.0f);
+    store_row8(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dv, 1.0f);
+  }
+}
+
 struct BlockCoord { int g, b, hg, blk; };   // hg = head-group index
 template <int HD>
 __device__ __forceinline__ BlockCoord locate(const AttnBatch& batch) {
@@ -178,15 +340,23 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   const int hoff = (wave % C::HG) * HD;          // this wave's head inside the staged group
   const int gcol = bc.hg * GC;                   // first column of the head group
   const int b = bc.b, hh = bc.hg * C::HG + wave % C::HG, H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
+  constexpr bool TAILS = HD == 8 && !CAUSAL;
+  const int tail_o = TAILS ? pr.tail_o : 0, tail_s = TAILS ? pr.tail_s : 0;
+  const int Tq_main = Tq - tail_o, Sk_main = Sk - tail_s;   // rows covered by MFMA tiles
   const int q0 = (bc.blk * C::TPB + wave / C::HG) * 32;
-  const bool active = q0 < Tq;
+  const bool active = q0 < Tq_main;
   const int q = q0 + r;
-  const bool qvalid = active && q < Tq;
+  const bool qvalid = active && q < Tq_main;
   const float scale = rsqrtf((float)HD);
   const float scale2 = scale * LOG2E;
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
   const bool dropping = batch.drop_p > 0.f;
+  if (TAILS && tail_o > 0 && bc.blk == 0) {
+    // the first workgroup of every (batch, head group) also serves the tail query rows, one head per wave
+    const TailCtx tc = {scale, scale2, dscale, thr, dropping};
+    for (int t = 0; t < tail_o; ++t) q_owner_tail<BWD>(pr, tc, b, hh, Tq_main + t, lane);
+  }
   const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)));
 
   bf16x8 qf[C::KS], dof[C::KS];
@@ -210,25 +380,34 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   float m = NEG_BIG, l = 0.f;
   f32x16 oacc = zero16();
 
-  for (int c0 = 0; c0 < Sk; c0 += KC) {
-    const int nvalid = min(KC, Sk - c0);
+  const int kvr = (!BWD && pr.kv_rows > 0) ? pr.kv_rows : Sk;
+  const bf16* kbatch = pr.K + (size_t)b * kvr * pr.ldk + gcol;
+  const bf16* vbatch = pr.V + (size_t)b * kvr * pr.ldv + gcol;
+  Staged kst, vst;
+  float bst = -INFINITY;
+  auto fetch = [&](int c0) {
+    const int nvalid = min(KC, Sk_main - c0);
+    stage_load(kst, kbatch + (size_t)c0 * pr.ldk, pr.ldk, nvalid, tid);
+    stage_load(vst, vbatch + (size_t)c0 * pr.ldv, pr.ldv, nvalid, tid);
+    bst = -INFINITY;
+    if (tid < nvalid) bst = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + tid] * LOG2E : 0.f;
+  };
+  constexpr bool PREFETCH = !BWD;   // the staging registers would spill in the dQ pass
+  if (PREFETCH) fetch(0);
+  for (int c0 = 0; c0 < Sk_main; c0 += KC) {
+    const int nvalid = min(KC, Sk_main - c0);
+    if (!PREFETCH) fetch(c0);
     __syncthreads();
-    const int kvr = (!BWD && pr.kv_rows > 0) ? pr.kv_rows : Sk;
-    const bf16* ksrc = pr.K + ((size_t)b * kvr + c0) * pr.ldk + gcol;
-    const bf16* vsrc = pr.V + ((size_t)b * kvr + c0) * pr.ldv + gcol;
     if (!BWD) {
-      stage<true, false>(Kimg, nullptr, ksrc, pr.ldk, nvalid, tid, nthr);
-      stage<false, true>(nullptr, Timg, vsrc, pr.ldv, nvalid, tid, nthr);
+      stage_store<true, false>(kst, Kimg, nullptr, tid);
+      stage_store<false, true>(vst, nullptr, Timg, tid);
     } else {
-      stage<true, true>(Kimg, Timg, ksrc, pr.ldk, nvalid, tid, nthr);
-      stage<true, false>(Vimg, nullptr, vsrc, pr.ldv, nvalid, tid, nthr);
+      stage_store<true, true>(kst, Kimg, Timg, tid);
+      stage_store<true, false>(vst, Vimg, nullptr, tid);
     }
-    for (int i = tid; i < KC; i += nthr) {
-      float bv = -INFINITY;
-      if (i < nvalid) bv = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + i] * LOG2E : 0.f;
-      bias[i] = bv;
-    }
+    if (tid < KC) bias[tid] = bst;
     __syncthreads();
+    if (PREFETCH && c0 + KC < Sk_main) fetch(c0 + KC);
     if (!active) continue;
     const int ntile = (nvalid + 31) >> 5;
     for (int t = 0; t < ntile; ++t) {
@@ -298,6 +477,37 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
     }
   }
   if (!qvalid) return;
+  if (TAILS && tail_s > 0) {
+    // tail keys: one score per query, both lane halves of a query compute it, each updates its own output half
+    const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * Tq + q) * pr.ldq + hh * HD);
+    bf16x8 dorow = qrow;
+    if (BWD) dorow = ldrow8(pr.dO + (size_t)(b * Tq + q) * pr.lddo + hh * HD);
+    for (int t = 0; t < tail_s; ++t) {
+      const int key = Sk_main + t;
+      const bf16x8 kt = ldrow8(pr.K + ((size_t)b * kvr + key) * pr.ldk + hh * HD);
+      const bf16x8 vt = ldrow8(pr.V + ((size_t)b * kvr + key) * pr.ldv + hh * HD);
+      const float bt = pr.kbias ? pr.kbias[(size_t)b * Sk + key] * LOG2E : 0.f;
+      const float sc = dot8(qrow, kt) * scale2 + bt;
+      const bool keep = !dropping || keep_of(rseed, key, thr);
+      if (!BWD) {
+        const float mn = fmaxf(m, sc);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        float p = __builtin_amdgcn_exp2f(sc - mn);
+        l = l * alpha + (h == 0 ? p : 0.f);
+        m = mn;
+        p = keep ? p * dscale : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oacc[j] = oacc[j] * alpha + p * (float)(h ? vt[4 + j] : vt[j]);
+      } else {
+        const float p = __builtin_amdgcn_exp2f(sc - lse2);
+        float dp = dot8(dorow, vt);
+        dp = keep ? dp * dscale : 0.f;
+        const float ds = p * (dp - delta) * scale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oacc[j] += ds * (float)(h ? kt[4 + j] : kt[j]);
+      }
+    }
+  }
   if (!BWD) {
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -332,15 +542,22 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   const float* lse_s = lse_all + hl * KC;
   const float* del_s = del_all + hl * KC;
   const uint32_t* rs_s = rs_all + hl * KC;
+  constexpr bool TAILS = HD == 8 && !CAUSAL;
+  const int tail_o = TAILS ? pr.tail_o : 0, tail_s = TAILS ? pr.tail_s : 0;
+  const int Sk_main = Sk - tail_o, Tq_main = Tq - tail_s;   // rows covered by MFMA tiles
   const int k0 = (bc.blk * C::TPB + wave / C::HG) * 32;
-  const bool active = k0 < Sk;
+  const bool active = k0 < Sk_main;
   const int key = k0 + r;
-  const bool kvalid = active && key < Sk;
+  const bool kvalid = active && key < Sk_main;
   const float scale = rsqrtf((float)HD);
   const float scale2 = scale * LOG2E;
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
   const bool dropping = batch.drop_p > 0.f;
+  if (TAILS && tail_o > 0 && bc.blk == 0) {
+    const TailCtx tc = {scale, scale2, dscale, thr, dropping};
+    for (int t = 0; t < tail_o; ++t) kv_owner_tail(pr, tc, b, hh, Sk_main + t, lane);
+  }
   const uint32_t pair_term = (uint32_t)(key >> 1) * ATTN_PAIR_MUL;
   const uint32_t pair_shift = (key & 1) ? 16u : 0u;
 
@@ -352,8 +569,8 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
 
   f32x16 dkacc = zero16(), dvacc = zero16();
 
-  for (int c0 = 0; c0 < Tq; c0 += KC) {
-    const int nvalid = min(KC, Tq - c0);
+  for (int c0 = 0; c0 < Tq_main; c0 += KC) {
+    const int nvalid = min(KC, Tq_main - c0);
     __syncthreads();
     stage<true, true>(Qimg, Qt, pr.Q + (size_t)(b * Tq + c0) * pr.ldq + gcol, pr.ldq, nvalid, tid, nthr);
     stage<true, true>(Dimg, Dt, pr.dO + (size_t)(b * Tq + c0) * pr.lddo + gcol, pr.lddo, nvalid, tid, nthr);
@@ -414,15 +631,48 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
     }
   }
   if (!kvalid) return;
+  if (TAILS && tail_s > 0) {
+    // tail queries: one score per key lane pair
+    const bf16x8 krow = ldrow8(pr.K + (size_t)(b * Sk + key) * pr.ldk + hh * HD);
+    const bf16x8 vrow = ldrow8(pr.V + (size_t)(b * Sk + key) * pr.ldv + hh * HD);
+    for (int t = 0; t < tail_s; ++t) {
+      const int qt = Tq_main + t;
+      const size_t stat = (size_t)(b * H + hh) * Tq + qt;
+      const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * Tq + qt) * pr.ldq + hh * HD);
+      const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * Tq + qt) * pr.lddo + hh * HD);
+      const float p = __builtin_amdgcn_exp2f(dot8(krow, qrow) * scale2 + bias2 - pr.lse[stat]);
+      float dp = dot8(vrow, dorow), pk = p;
+      if (dropping) {
+        const bool keep = keep_of(attn_row_seed(pr.seed, (uint32_t)stat), key, thr);
+        dp = keep ? dp * dscale : 0.f;
+        pk = keep ? p * dscale : 0.f;
+      }
+      const float ds = p * (dp - pr.delta[stat]) * scale;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dvacc[j] += pk * (float)(h ? dorow[4 + j] : dorow[j]);
+        dkacc[j] += ds * (float)(h ? qrow[4 + j] : qrow[j]);
+      }
+    }
+  }
   store_rows<HD>(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dkacc, 1.0f, h);
   store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
 }
 
+// rows of a side that are handled outside the MFMA tiling (see "Tail rows" above)
+int tail_of(const AttnBatch& b, int rows) {
+  static const int enabled = [] { const char* e = getenv("MMST_ATTN_TAILS"); return e ? atoi(e) : 1; }();
+  const int r = rows & 31;
+  return (enabled && b.hd == 8 && !b.causal && rows >= 64 && r >= 1 && r <= 2) ? r : 0;
+}
+
 // workgroups per (batch, head group): one per TPB owner tiles
-void plan(const AttnBatch& b, bool owner_is_key, int (&bpb)[ATTN_MAX_GROUPS]) {
+void plan(AttnBatch& b, bool owner_is_key, int (&bpb)[ATTN_MAX_GROUPS]) {
   const int tpb = b.hd == 32 ? Cfg<32>::TPB : Cfg<8>::TPB;
   for (int i = 0; i < b.n; ++i) {
-    int rows = owner_is_key ? b.p[i].Sk : b.p[i].Tq;
+    b.p[i].tail_o = tail_of(b, owner_is_key ? b.p[i].Sk : b.p[i].Tq);
+    b.p[i].tail_s = tail_of(b, owner_is_key ? b.p[i].Tq : b.p[i].Sk);
+    int rows = (owner_is_key ? b.p[i].Sk : b.p[i].Tq) - b.p[i].tail_o;
     int tiles = (rows + 31) / 32;
     bpb[i] = (tiles + tpb - 1) / tpb;
   }
