@@ -1,6 +1,7 @@
 // Fused feed-forward kernels, see ffn.h.
 //
-// Workgroup = 128 token rows, 4 waves, each wave owns 32 whole rows (the layout of the LayerNorm epilogues).
+// Workgroup = 128 token rows as 8 waves of 16 whole rows (or 160 rows / 10 waves, or 4 waves of 32 rows: see
+// Shape<>); a wave owns whole rows, the layout of the LayerNorm epilogues.
 // The hidden dimension is walked in 32 chunks of 64 columns.  Per chunk a fixed sequence of 16 KiB LDS images
 // is consumed, one barrier each:
 //   forward   [W1 chunk: 64 hidden x 128 model, both contraction halves side by side] [W2 chunk: 128 model x 64 hidden]
@@ -24,6 +25,19 @@ namespace {
 constexpr int DM = 128, FF = 2048, HC = 64, NCHUNK = FF / HC;
 constexpr int SLOT = 16384, NSLOT = 4, AHEAD = 3;
 
+// Workgroup shapes (NW = waves): 4 waves x 32 rows, 8 waves x 16 rows (128-row tiles) or 10 waves x 16 rows
+// (160-row tiles: a launch of 257..320 128-row tiles would need a second, mostly empty round of workgroups).
+// The 16 DMA instructions of a weight image are issued by the first 16/WD waves, WD each; every wave brings in
+// its own rows of a hidden-activation image.
+template <int NW> struct Shape {
+  static constexpr int MT = NW == 4 ? 2 : 1;        // 16-row MFMA tiles per wave
+  static constexpr int BPX = NW * 16 * MT;          // rows per workgroup
+  static constexpr int WD = NW == 4 ? 4 : 2;        // weight-image DMA instructions per issuing wave
+  static constexpr int NWD = 16 / WD;               // issuing waves
+  static constexpr int HD = 2 * MT;                 // hidden-image DMA instructions (and hidden stores) per wave
+  static constexpr int RSLOT = BPX * 128 > SLOT ? BPX * 128 : SLOT;   // ring slot of the backward kernel
+};
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -36,13 +50,12 @@ __device__ __forceinline__ void glds16(const bf16* src, unsigned char* dst) {
 
 enum ImgKind { IMG_W1_FWD, IMG_W2_FWD, IMG_H_BWD };
 
-// Per-lane element offset (relative to chunk 0) of the 16 bytes lane `lane` of wave `wave` contributes to DMA
-// instruction j (0..3) of an image.  Row-major images: 8 rows of 128 B per instruction; contraction-major
-// images: 4 rows of 256 B per instruction.
+// Per-lane element offset (relative to chunk 0) of the 16 bytes lane `lane` contributes to the DMA instruction
+// that fills image rows r0 .. r0+7 (8 rows of 128 B per instruction).
 template <int KIND>
-__device__ __forceinline__ uint32_t src_offset(int wave, int lane, int j, int p0, int M) {
+__device__ __forceinline__ uint32_t src_offset(int r0, int lane, int p0, int M) {
   {
-    const int r = wave * 32 + j * 8 + (lane >> 3), s = lane & 7;
+    const int r = r0 + (lane >> 3), s = lane & 7;
     if (KIND == IMG_W1_FWD) return (uint32_t)((r & 63) * DM + (r >> 6) * 64 + ((s ^ fsw(r)) << 3));
     if (KIND == IMG_W2_FWD) return (uint32_t)(r * FF + ((s ^ fsw(r)) << 3));
     const int m = (p0 + r < M) ? p0 + r : M - 1;
@@ -62,9 +75,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //   dh = g * mask(h)  mask = saved hidden activation > 0 (ReLU and dropout at once), h tile by LDS-DMA
 //   dx += dh W1       second GEMM, weight image from W1^T [128][2048]
 // Three images per chunk through a ring of four slots, three images ahead, one barrier per image.
-template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT];
+template <bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const FfnBatch batch) {
+  typedef Shape<NW> S;
+  constexpr int MT = S::MT, WD = S::WD, HD = S::HD, RSLOT = S::RSLOT;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * RSLOT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0;
@@ -75,16 +90,16 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
   const int M = pr.epi.Pn;
   const int local = (int)blockIdx.x - pr.tile_begin;
   const int hsplit = SPLIT ? pr.hsplit : 1;
-  const int p0 = (local / hsplit) * BP;
+  const int p0 = (local / hsplit) * S::BPX;
   const int hs = local % hsplit;                      // this workgroup walks hidden chunks [c0, c1)
   const int c0 = SPLIT ? hs * NCHUNK / hsplit : 0, c1 = SPLIT ? (hs + 1) * NCHUNK / hsplit : NCHUNK;
-  const int pw0 = wave * 32;
+  const int pw0 = wave * 16 * MT;
   const int q = lane >> 4;
 
-  bf16x8 xf[2][4];
-  uint32_t hoff[2];
+  bf16x8 xf[MT][4];
+  uint32_t hoff[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -100,38 +115,57 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  f32x4 acc[2][8];
+  f32x4 acc[MT][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int NIMG = 3;
   const int TOTAL = (c1 - c0) * NIMG;
-  uint32_t offA[4], offB[4], offH[4];
+  const bool wdma = NW == S::NWD || wave < S::NWD;   // this wave issues weight-image DMA
+  uint32_t offA[WD], offB[WD], offH[HD];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    offA[j] = src_offset<IMG_W1_FWD>(wave, lane, j, p0, M);
-    offB[j] = src_offset<IMG_W2_FWD>(wave, lane, j, p0, M);
-    offH[j] = src_offset<IMG_H_BWD>(wave, lane, j, p0, M);
+  for (int j = 0; j < WD; ++j) {
+    offA[j] = src_offset<IMG_W1_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
+    offB[j] = src_offset<IMG_W2_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
   }
+#pragma unroll
+  for (int j = 0; j < HD; ++j) offH[j] = src_offset<IMG_H_BWD>(pw0 + j * 8, lane, p0, M);
   // image i of the sequence = phase (i % 3) of chunk (i / 3), into ring slot (i % 4)
   auto issue = [&](int c, int ph, int i) {
-    unsigned char* dst = smem + (i & (NSLOT - 1)) * SLOT + wave * (SLOT / 4);
+    unsigned char* slot = smem + (i & (NSLOT - 1)) * RSLOT;
+    if (ph == 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16* src = ph == 0 ? pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
-                      : ph == 1 ? pr.H + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>()
-                                : pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
-      glds16(src, dst + j * 1024);
+      for (int j = 0; j < HD; ++j)
+        glds16(pr.H + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>(), slot + (pw0 + j * 8) * 128);
+    } else if (wdma) {
+#pragma unroll
+      for (int j = 0; j < WD; ++j) {
+        const bf16* src = ph == 0 ? pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
+                                  : pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
+        glds16(src, slot + (wave * WD + j) * 1024);
+      }
     }
   };
   // Own DMA portions of image i have landed once only what was issued after them is outstanding: the two younger
-  // images (8 DMA instructions) and the 4 dh stores of the one mask step among the last three steps.
-  auto wait_image = [&](int i) {
-    if (i + 2 < TOTAL) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (i + 1 < TOTAL) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // images and the hidden-gradient stores of the one mask step among the last three steps (all three kinds count
+  // WD = HD instructions on a wave that issues weight images).  A wave that only brings in hidden-activation rows
+  // has, behind such an image, just the stores of the previous mask step.
+  auto wait_image = [&](int i, int ph) {
+    if (!wdma) {
+      if (ph == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      return;
+    }
+    if (i + 2 < TOTAL) {
+      if (WD == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (i + 1 < TOTAL) {
+      if (WD == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   };
   auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
@@ -139,40 +173,41 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
   issue(c0, 0, 0);
   issue(c0, 1, 1);
   issue(c0, 2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counted waits below assume a full pipeline behind them
 
   for (int c = c0; c < c1; ++c) {
     int i = (c - c0) * NIMG;
-    f32x4 a1[2][4];
+    f32x4 a1[MT][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) a1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      wait_image(i);
+      wait_image(i, 0);
       __builtin_amdgcn_s_barrier();
       if (i + AHEAD < TOTAL) issue(c + 1, 0, i + AHEAD);
-      const unsigned char* img = smem + (i & (NSLOT - 1)) * SLOT;
+      const unsigned char* img = smem + (i & (NSLOT - 1)) * RSLOT;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 qf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) qf[nt] = frag_n<true>(img, (ks >> 1) * 64 + qrow(nt), ks & 1, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
             a1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], xf[mt][ks], a1[mt][nt], 0, 0, 0);
       }
       ++i;
     }
-    bf16x8 hf[2][2];
+    bf16x8 hf[MT][2];
     {
-      wait_image(i);
+      wait_image(i, 1);
       __builtin_amdgcn_s_barrier();
       if (i + AHEAD < TOTAL) issue(c + 1, 1, i + AHEAD);
-      const unsigned char* himg = smem + (i & (NSLOT - 1)) * SLOT;
+      const unsigned char* himg = smem + (i & (NSLOT - 1)) * RSLOT;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
           bf16x8 h = frag_n<false>(himg, pw0 + mt * 16 + (lane & 15), tp, lane);
@@ -189,17 +224,17 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
       ++i;
     }
     {
-      wait_image(i);
+      wait_image(i, 2);
       __builtin_amdgcn_s_barrier();
       if (i + AHEAD < TOTAL) issue(c + 1, 2, i + AHEAD);
-      const unsigned char* img = smem + (i & (NSLOT - 1)) * SLOT;
+      const unsigned char* img = smem + (i & (NSLOT - 1)) * RSLOT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 qf[8];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) qf[nt] = frag_n<true>(img, qrow(nt), ks, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], hf[mt][ks], acc[mt][nt], 0, 0, 0);
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
     store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
   } else {
     __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
-    epi_lnbwd(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
   }
 }
 
@@ -221,8 +256,10 @@ __global__ __launch_bounds__(256, 2) void ffn_bwd_kernel(const FfnBatch batch) {
 //   second GEMM of chunk c-1         (MFMA, image W2(c-1), operand = bf16 hidden fragments of the previous step)
 //   bias/ReLU/dropout of chunk c     (VALU, fills the MFMA shadow) -> store + fragments for the next step
 // LDS: two slots per weight (the image being read, the image in flight), filled right after the barrier.
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
+template <bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const FfnBatch batch) {
+  typedef Shape<NW> S;
+  constexpr int MT = S::MT, WD = S::WD;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4];
   unsigned char* w1s = smem;             // 2 slots
   unsigned char* w2s = smem + 2 * SLOT;  // 2 slots
@@ -236,16 +273,16 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   const FfnProb& pr = batch.p[g];
   const int M = pr.epi.Pn;
   const int local = (int)blockIdx.x - pr.tile_begin;
-  const int p0 = (local / pr.hsplit) * BP;
+  const int p0 = (local / pr.hsplit) * S::BPX;
   const int hs = local % pr.hsplit;                   // this workgroup walks hidden chunks [c0, c1)
   const int c0 = hs * NCHUNK / pr.hsplit, c1 = (hs + 1) * NCHUNK / pr.hsplit;
-  const int pw0 = wave * 32;
+  const int pw0 = wave * 16 * MT;
   const int q = lane >> 4;
 
-  bf16x8 xf[2][4];
-  uint32_t hoff[2], rseed[2];
+  bf16x8 xf[MT][4];
+  uint32_t hoff[MT], rseed[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -256,33 +293,35 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
     hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;   // byte offset; rows >= M fall outside the descriptor and are dropped
     rseed[mt] = attn_row_seed(pr.seed, (uint32_t)m);
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-    *reinterpret_cast<f32x4*>(b1s + (tid + 256 * i) * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + (tid + 256 * i) * 4);
+  for (int i = tid; i < FF / 4; i += NW * 64)
+    *reinterpret_cast<f32x4*>(b1s + i * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + i * 4);
   // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
   const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
 
-  f32x4 acc[2][8];
+  f32x4 acc[MT][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint32_t offA[4], offB[4];
+  const bool wdma = NW == S::NWD || wave < S::NWD;   // this wave issues weight-image DMA
+  uint32_t offA[WD], offB[WD];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    offA[j] = src_offset<IMG_W1_FWD>(wave, lane, j, p0, M);
-    offB[j] = src_offset<IMG_W2_FWD>(wave, lane, j, p0, M);
+  for (int j = 0; j < WD; ++j) {
+    offA[j] = src_offset<IMG_W1_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
+    offB[j] = src_offset<IMG_W2_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
   }
   auto issue_w1 = [&](int c) {
-    unsigned char* dst = w1s + (c & 1) * SLOT + wave * (SLOT / 4);
+    unsigned char* dst = w1s + (c & 1) * SLOT + wave * WD * 1024;
+    if (wdma)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
+      for (int j = 0; j < WD; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
   };
   auto issue_w2 = [&](int c) {
-    unsigned char* dst = w2s + (c & 1) * SLOT + wave * (SLOT / 4);
+    unsigned char* dst = w2s + (c & 1) * SLOT + wave * WD * 1024;
+    if (wdma)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
+      for (int j = 0; j < WD; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
   };
   auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
 
@@ -290,12 +329,12 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   const uint32_t thr = drop_threshold(pr.drop_p);
   const uint32_t lane_pt = (uint32_t)(4 * q) * ATTN_PAIR_MUL;
 
-  f32x4 a1[2][4];
-  bf16x8 hfp[2][2];
+  f32x4 a1[MT][4];
+  bf16x8 hfp[MT][2];
   auto gemm1 = [&](int c) {
     const unsigned char* img = w1s + (c & 1) * SLOT;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) a1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -304,21 +343,22 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) qf[nt] = frag_n<true>(img, (ks >> 1) * 64 + qrow(nt), ks & 1, lane);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           a1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], xf[mt][ks], a1[mt][nt], 0, 0, 0);
     }
   };
-  // Second GEMM of chunk c2 and hidden-chunk arithmetic of chunk c in ONE hand-ordered region: the 32 MFMAs go out
-  // two at a time, each pair followed by one 2-column piece of the bias/ReLU/dropout/convert work (16 pieces), so
-  // the vector ALU runs in the shadow of the matrix pipe.  c2 < 0: arithmetic only.  c < 0: MFMAs only.
+  // Second GEMM of chunk c2 and hidden-chunk arithmetic of chunk c in ONE hand-ordered region: the 16 MT MFMAs go
+  // out MT at a time, each group followed by one 2-column piece of the bias/ReLU/dropout/convert work (8 MT pieces
+  // over 16 slots), so the vector ALU runs in the shadow of the matrix pipe.  c2 < 0: arithmetic only.  c < 0:
+  // MFMAs only.
   auto gemm2_hidden = [&](int c2, int c) {
     const unsigned char* img = w2s + (c2 & 1) * SLOT;
     const uint32_t chunk_pt = (uint32_t)(c * (HC / 2)) * ATTN_PAIR_MUL;
     bf16x8 qf[2][4];
     float bv[2][8];
-    uint32_t hn[2][2][4];
+    uint32_t hn[MT][2][4];
     if (c2 >= 0) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) qf[0][nt] = frag_n<true>(img, qrow(nt), 0, lane);
@@ -339,12 +379,14 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
       for (int j = 0; j < 4; ++j) {
         if (c2 >= 0) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
             acc[mt][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[grp & 1][j], hfp[mt][ks], acc[mt][nt0 + j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c >= 0) {
-          const int piece = grp * 4 + j, tp = piece >> 3, mt = (piece >> 2) & 1, e = (piece & 3) * 2;
+        const int slot = grp * 4 + j;
+        if (c >= 0 && (MT == 2 || (slot & 1) == 0)) {
+          const int piece = MT == 2 ? slot : slot >> 1;
+          const int tp = MT == 2 ? piece >> 3 : piece >> 2, mt = MT == 2 ? (piece >> 2) & 1 : 0, e = (piece & 3) * 2;
           float v0 = a1[mt][2 * tp + (e >> 2)][e & 3], v1 = a1[mt][2 * tp + (e >> 2)][(e & 3) + 1];
           v0 = fmaxf(v0 + bv[tp][e], 0.f);
           v1 = fmaxf(v1 + bv[tp][e + 1], 0.f);
@@ -367,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
     }
     if (c >= 0) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
           u32x4 o = {hn[mt][tp][0], hn[mt][tp][1], hn[mt][tp][2], hn[mt][tp][3]};
@@ -387,9 +429,12 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   gemm1(c0);
   gemm2_hidden(-1, c0);
 
+  auto wait_images = [&]() {   // everything older than the 2 MT hidden-activation stores of the previous step
+    if (MT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
   for (int c = c0 + 1; c < c1; ++c) {
-    // everything older than the 4 hidden-activation stores of the previous step has landed: both images of this step
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    wait_images();   // both images of this step have landed
     __builtin_amdgcn_s_barrier();
     if (c + 1 < c1) issue_w1(c + 1);
     issue_w2(c);
@@ -397,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
     __builtin_amdgcn_sched_barrier(0);
     gemm2_hidden(c - 1, c);
   }
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  wait_images();
   __builtin_amdgcn_s_barrier();
   gemm2_hidden(c1 - 1, -1);
 
@@ -405,18 +450,18 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_kernel(const FfnBatch batch) {
   else epi_ln(acc, pr.epi, p0, pw0, lane);
 }
 
-int prepare(FfnBatch& b, bool bwd) {
+int prepare(FfnBatch& b, bool bwd, int bpx) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return -1;
   int tiles = 0;
   bool have_ws = true;
   for (int i = 0; i < b.n; ++i) {
     FfnProb& p = b.p[i];
-    if (((long)p.epi.Pn + BP) * FF * 2 >= (1L << 31)) return -1;   // 32-bit byte offsets into the hidden activation
+    if (((long)p.epi.Pn + bpx) * FF * 2 >= (1L << 31)) return -1;   // 32-bit byte offsets into the hidden activation
     if (p.epi.Pn <= 0 || !p.X || !p.W1 || !p.W2 || !p.H || !p.epi.C) return -1;
     if (!bwd && (!p.b1 || !p.epi.gamma || !p.epi.beta)) return -1;
     if (bwd && (!p.epi.gamma || !p.epi.Z || !p.epi.stats)) return -1;
     p.epi.Qn = DM;
-    tiles += (p.epi.Pn + BP - 1) / BP;
+    tiles += (p.epi.Pn + bpx - 1) / bpx;
     have_ws = have_ws && p.ws != nullptr;
   }
   // few row tiles: split the hidden dimension over up to FFN_MAX_HSPLIT workgroups per tile (needs the workspace)
@@ -428,7 +473,7 @@ int prepare(FfnBatch& b, bool bwd) {
     FfnProb& p = b.p[i];
     p.hsplit = hsplit;
     p.tile_begin = total;
-    total += ((p.epi.Pn + BP - 1) / BP) * hsplit;
+    total += ((p.epi.Pn + bpx - 1) / bpx) * hsplit;
   }
   return total;
 }
@@ -498,6 +543,14 @@ int fuse_min_tiles() {
   return g_fuse_min_tiles;
 }
 
+// Rows per wave of the fused kernels: 16 (8 or 10 waves per tile: two to three waves per SIMD to hide the
+// dependent LDS/MFMA latencies behind, at twice the LDS fragment traffic) or 32 (4 waves per 128-row tile).
+// Environment: MMST_FFN_WAVE_ROWS.
+int wave_rows() {
+  static const int v = [] { const char* e = getenv("MMST_FFN_WAVE_ROWS"); return (e && atoi(e) == 32) ? 32 : 16; }();
+  return v;
+}
+
 int ffn_fwd_unfused(FfnBatch& b, hipStream_t stream) {
   GemmBatch g1, g2;
   g1.n = g2.n = b.n;
@@ -541,29 +594,58 @@ int ffn_bwd_unfused(FfnBatch& b, hipStream_t stream) {
   return launch_gemm(g2, EPI_LNBWD, false, false, stream);
 }
 
+// Workgroup shape of a fused launch: 8 waves of 16 rows; 10 waves when that brings a launch of more than 256
+// 128-row tiles down to one workgroup per CU; MMST_FFN_WAVE_ROWS=32 selects the 4-wave shape.
+int pick_waves(const FfnBatch& b) {
+  if (wave_rows() == 32) return 4;
+  int t128 = 0, t160 = 0;
+  for (int i = 0; i < b.n; ++i) {
+    t128 += (b.p[i].epi.Pn + 127) / 128;
+    t160 += (b.p[i].epi.Pn + 159) / 160;
+  }
+  return (t128 > 256 && t160 <= 256) ? 10 : 8;
+}
+
+template <int NW>
+void launch_fwd_shape(const FfnBatch& b, int total, bool drop, hipStream_t stream) {
+  if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_fwd_kernel<false, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+}
+template <int NW>
+void launch_bwd_shape(const FfnBatch& b, int total, bool split, hipStream_t stream) {
+  if (split) hipLaunchKernelGGL((ffn_bwd_kernel<true, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+  else hipLaunchKernelGGL((ffn_bwd_kernel<false, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+}
+
 }  // namespace
 
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
-  int total = prepare(b, false);
+  if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
+  const int nw = pick_waves(b);
+  int total = prepare(b, false, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
   if (!split && total < fuse_min_tiles()) return ffn_fwd_unfused(b, stream);
   bool drop = false;
   for (int i = 0; i < b.n; ++i) drop = drop || b.p[i].drop_p > 0.f;
-  if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
-  else hipLaunchKernelGGL((ffn_fwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
+  if (nw == 4) launch_fwd_shape<4>(b, total, drop, stream);
+  else if (nw == 8) launch_fwd_shape<8>(b, total, drop, stream);
+  else launch_fwd_shape<10>(b, total, drop, stream);
   MMST_CHECK_LAUNCH();
   if (split) return row_epilogue(b, false, stream);
   return MMST_OK;
 }
 
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
-  int total = prepare(b, true);
+  if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
+  const int nw = pick_waves(b);
+  int total = prepare(b, true, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
   if (!split && total < fuse_min_tiles()) return ffn_bwd_unfused(b, stream);
-  if (split) hipLaunchKernelGGL((ffn_bwd_kernel<true>), dim3(total), dim3(256), 0, stream, b);
-  else hipLaunchKernelGGL((ffn_bwd_kernel<false>), dim3(total), dim3(256), 0, stream, b);
+  if (nw == 4) launch_bwd_shape<4>(b, total, split, stream);
+  else if (nw == 8) launch_bwd_shape<8>(b, total, split, stream);
+  else launch_bwd_shape<10>(b, total, split, stream);
   MMST_CHECK_LAUNCH();
   if (split) return row_epilogue(b, true, stream);
   return MMST_OK;

@@ -128,10 +128,11 @@ __device__ __forceinline__ void drop8(float (&v)[8], uint32_t seed, uint32_t idx
 }
 
 // ---- fp32 partial sums of a row-owning accumulator (4x1 wave layout): slab s holds [rows][128] floats ----
-__device__ __forceinline__ void store_slab(const f32x4 (&acc)[2][8], float* slab, int rows, int p0, int pw0, int lane) {
+template <int MT>
+__device__ __forceinline__ void store_slab(const f32x4 (&acc)[MT][8], float* slab, int rows, int p0, int pw0, int lane) {
   const int q = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
     if (m >= rows) continue;
 #pragma unroll
@@ -143,12 +144,12 @@ __device__ __forceinline__ void store_slab(const f32x4 (&acc)[2][8], float* slab
   }
 }
 // acc += slabs s0, s0 + stride, ... (< n) for the 32 rows at p0 + pw0; all loads of a call are independent
-template <int MAXS>
-__device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs, int s0, int stride, int n, int rows,
+template <int MAXS, int MT>
+__device__ __forceinline__ void add_slabs(f32x4 (&acc)[MT][8], const float* slabs, int s0, int stride, int n, int rows,
                                           int p0, int pw0, int lane) {
   const int q = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
     if (m >= rows) continue;
 #pragma unroll
@@ -165,10 +166,11 @@ __device__ __forceinline__ void add_slabs(f32x4 (&acc)[2][8], const float* slabs
   }
 }
 
-// ---- LayerNorm forward on a 4x1 wave layout: acc[mt][nt] holds rows p0+pw0+mt*16+(lane&15), all 128 columns.
+// ---- LayerNorm forward on a row-owning wave layout: acc[mt][nt] holds rows p0+pw0+mt*16+(lane&15), all 128
+// columns (MT = 2: 4 waves x 32 rows, MT = 1: 8 waves x 16 rows).
 // z = R + drop(acc + bias); C = LN(z) (row remap cS/cL/coff); Z = z; stats = (mean, rstd).
-__device__ __forceinline__ void epi_ln(f32x4 (&acc)[2][8], const GemmProb& pr, int p0, int pw0, int lane) {
-  constexpr int MT = 2;
+template <int MT>
+__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, int p0, int pw0, int lane) {
   const int q = lane >> 4;
   auto crow = [&](int m) -> size_t { return pr.cS > 0 ? (size_t)(m / pr.cS) * pr.cL + pr.coff + (m % pr.cS) : (size_t)m; };
   auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
@@ -234,12 +236,11 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[2][8], const GemmProb& pr, i
 }
 
 // ---- LayerNorm backward on the same layout: dy = acc + R; C = dz, C2 = drop(dz); dgamma/dbeta column sums
-// (in-wave shuffles, then the 4 waves through `smem`, >= 4 KiB, which must be free of live data).
-// NW = waves of the workgroup (4: 128-row tile, 1: a single wave with its 32 rows).
-template <int NW = 4>
-__device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[2][8], const GemmProb& pr, int p0, int pw0, int lane, int wave,
+// (in-wave shuffles, then the NW waves through `smem`, >= NW KiB, which must be free of live data).
+// NW = waves of the workgroup that call it (4 or 8: 128-row tile, 1: a single wave with its rows).
+template <int NW = 4, int MT>
+__device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[MT][8], const GemmProb& pr, int p0, int pw0, int lane, int wave,
                                           int tid, unsigned char* smem) {
-  constexpr int MT = 2;
   const int q = lane >> 4;
   auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
   const uint32_t thr = drop_threshold(pr.drop_p);
@@ -326,7 +327,7 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[2][8], const GemmProb& pr
         pb[tp][e] = b;
       }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][128]
+    float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][128]
     if ((lane & 15) == 0) {
 #pragma unroll
       for (int tp = 0; tp < 4; ++tp)

@@ -205,10 +205,13 @@ def ffn_keep_mask(seed, M, N, p):
 
 
 @pytest.mark.parametrize("fused", [True, False, "split"])
-@pytest.mark.parametrize("M,groups,p", [(300, 1, 0.0), (1000, 2, 0.1), (129, 3, 0.0)])
+@pytest.mark.parametrize("M,groups,p", [(300, 1, 0.0), (1000, 2, 0.1), (129, 3, 0.0), (33000, 1, 0.1), (16500, 2, 0.0)])
 def test_ffn_fwd_bwd(fused, M, groups, p):
     """y = LN(x + drop(W2 drop(relu(W1 x + b1)) + b2)) and its activation-gradient pass, fused kernels and the
-    two-launch path, against fp32 torch math on the same bf16 operands (hidden dropout mask taken from h)."""
+    two-launch path, against fp32 torch math on the same bf16 operands (hidden dropout mask taken from h).
+    The two large cases need more than 256 128-row tiles, i.e. the 160-row workgroup shape."""
+    if M > 10000 and fused is not True:
+        pytest.skip("large case exercises the fused kernels only")
     L.check(L.lib().mmst_ffn_config(0 if fused else 1 << 20), "cfg")
     try:
         fw, bw, keepers = [], [], []
@@ -242,11 +245,14 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
             Mg = x.shape[0]
             pre = torch.relu(x.float() @ w1.float().t() + b1)
             if p > 0:
-                if fused:
+                if Mg > 10000:   # too many elements for the numpy hash: take the mask from h, check its rate
+                    keep = (h != 0) | (pre < 0.05)
+                    assert abs(keep[pre >= 0.05].float().mean().item() - (1 - p)) < 0.002
+                elif fused:
                     keep = torch.from_numpy(ffn_keep_mask(100 + gi, Mg, 2048, p)).to(DEV)
                 else:
                     keep = torch.from_numpy(keep_mask(100 + gi, np.arange(Mg * 2048), p).reshape(Mg, 2048)).to(DEV)
-                assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+                assert abs(keep.float().mean().item() - (1 - p)) < 0.01 or Mg > 10000
                 pre = pre * keep / (1 - p)
             close(h, pre)
             out = h.float() @ w2.float().t() + b2

@@ -1,6 +1,7 @@
 import csv, glob, collections, sys
 tag = sys.argv[1]
-f = glob.glob(f'/root/repo/gpurun_out/{tag}/trace/*/*kernel_trace.csv')[0]
+import os
+f = max(glob.glob(f'/root/repo/gpurun_out/{tag}/trace/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(list)
 for r in rows:
