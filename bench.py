@@ -116,6 +116,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("MMST_BENCH_HP_STREAM") == "1":   # experiment: critical path on a high-priority stream
+        hp = torch.cuda.Stream(priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for i in range(args.warmup):
         tm.training_step(batches[i % len(batches)], i)
     sync()

@@ -448,8 +448,8 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
             uint32_t hb = attn_pair_bits(tbase, (uint32_t)(acc_row(i, 0) >> 1) * ATTN_PAIR_MUL);
-            pv[i] = ((hb & 0xFFFFu) >= thr) ? pv[i] * dscale : 0.f;
-            pv[i + 1] = ((hb >> 16) >= thr) ? pv[i + 1] * dscale : 0.f;
+            pv[i] = ((hb & 0xFFFFu) >= thr) ? pv[i] : 0.f;       // 1/(1-p) is applied once, to the output row
+            pv[i + 1] = ((hb >> 16) >= thr) ? pv[i + 1] : 0.f;
           }
         }
       } else {
@@ -495,7 +495,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
         float p = __builtin_amdgcn_exp2f(sc - mn);
         l = l * alpha + (h == 0 ? p : 0.f);
         m = mn;
-        p = keep ? p * dscale : 0.f;
+        p = keep ? p : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) oacc[j] = oacc[j] * alpha + p * (float)(h ? vt[4 + j] : vt[j]);
       } else {
@@ -510,7 +510,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
   }
   if (!BWD) {
     l += __shfl_xor(l, 32);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const float inv = l > 0.f ? dscale / l : 0.f;
     store_rows<HD>(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, oacc, inv, h);
     if (h == 0) pr.lse[(size_t)(b * H + hh) * Tq + q] = m + __builtin_amdgcn_logf(l);
   } else {

@@ -43,19 +43,22 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
 }
 // Row-seeded dropout (attention probabilities; hidden activation of the fused feed-forward block): the mask
 // bit of (row, column) is a function of a per-row seed (one full mix per row) and the column PAIR (one cheap
-// mix per pair, 16 bits per column), so it costs one integer multiply per two elements and can be regenerated
-// from any register layout.
+// mix per pair, 16 bits per column), and can be regenerated from any register layout.  The pair mix is built
+// from full-rate instructions only: a 24-bit multiply (v_mul_u32_u24; the 32-bit v_mul_lo_u32 issues at quarter
+// rate) between two xor-folds by 16 bits (one sub-dword-select instruction each); the 16-bit halves of the result
+// are compared with sub-dword selects as well.
+#define ATTN_PAIR_MUL 0x85EBCA6BU
+#define ATTN_PAIR_K24 0x9E3779U
 __device__ __forceinline__ uint32_t attn_row_seed(uint32_t seed, uint32_t rowid) {
   return mix32(seed + rowid * 0x9E3779B9U);
 }
 __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t row_seed, uint32_t pair_term) {
   uint32_t t = row_seed + pair_term;   // pair_term = (key >> 1) * ATTN_PAIR_MUL
   t ^= t >> 16;
-  t *= 0x7feb352dU;
-  t ^= t >> 15;
+  t = __umul24(t, ATTN_PAIR_K24);      // low 24 bits of t times a 24-bit constant, low 32 bits of the product
+  t ^= t >> 16;
   return t;
 }
-#define ATTN_PAIR_MUL 0x85EBCA6BU
 
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);

@@ -293,8 +293,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
     hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;   // byte offset; rows >= M fall outside the descriptor and are dropped
     rseed[mt] = attn_row_seed(pr.seed, (uint32_t)m);
   }
+  // relu(a + b) * s == relu(a * s + b * s) for s > 0: the bias is staged pre-multiplied by the dropout scale
+  const float dscale = (DROP && pr.drop_p > 0.f) ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
   for (int i = tid; i < FF / 4; i += NW * 64)
-    *reinterpret_cast<f32x4*>(b1s + i * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + i * 4);
+    *reinterpret_cast<f32x4*>(b1s + i * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + i * 4) * dscale;
   // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
   const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
 
@@ -325,7 +327,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   };
   auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
 
-  const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
   const uint32_t thr = drop_threshold(pr.drop_p);
   const uint32_t lane_pt = (uint32_t)(4 * q) * ATTN_PAIR_MUL;
 
@@ -388,12 +389,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
           const int piece = MT == 2 ? slot : slot >> 1;
           const int tp = MT == 2 ? piece >> 3 : piece >> 2, mt = MT == 2 ? (piece >> 2) & 1 : 0, e = (piece & 3) * 2;
           float v0 = a1[mt][2 * tp + (e >> 2)][e & 3], v1 = a1[mt][2 * tp + (e >> 2)][(e & 3) + 1];
-          v0 = fmaxf(v0 + bv[tp][e], 0.f);
-          v1 = fmaxf(v1 + bv[tp][e + 1], 0.f);
+          v0 = fmaxf(fmaf(v0, dscale, bv[tp][e]), 0.f);
+          v1 = fmaxf(fmaf(v1, dscale, bv[tp][e + 1]), 0.f);
           if (DROP) {
             const uint32_t hb = attn_pair_bits(rseed[mt] + lane_pt + chunk_pt, (uint32_t)(tp * 16 + (e >> 1)) * ATTN_PAIR_MUL);
-            v0 = ((hb & 0xFFFFu) >= thr) ? v0 * dscale : 0.f;
-            v1 = ((hb >> 16) >= thr) ? v1 * dscale : 0.f;
+            v0 = ((hb & 0xFFFFu) >= thr) ? v0 : 0.f;
+            v1 = ((hb >> 16) >= thr) ? v1 : 0.f;
           }
           bf16x2 o2;
           o2[0] = (bf16)v0;
@@ -545,10 +546,13 @@ int fuse_min_tiles() {
 
 // Rows per wave of the fused kernels: 16 (8 or 10 waves per tile: two to three waves per SIMD to hide the
 // dependent LDS/MFMA latencies behind, at twice the LDS fragment traffic) or 32 (4 waves per 128-row tile).
-// Environment: MMST_FFN_WAVE_ROWS.
-int wave_rows() {
-  static const int v = [] { const char* e = getenv("MMST_FFN_WAVE_ROWS"); return (e && atoi(e) == 32) ? 32 : 16; }();
-  return v;
+// The forward pass runs alone on the GPU and takes the 16-row shape; the backward kernels share the CUs with the
+// weight-gradient stream, which already fills their idle issue slots, and measured slightly better with the
+// lighter 4-wave shape.  Environment: MMST_FFN_WAVE_ROWS_FWD / MMST_FFN_WAVE_ROWS_BWD (16 or 32).
+int wave_rows(bool bwd) {
+  static const int f = [] { const char* e = getenv("MMST_FFN_WAVE_ROWS_FWD"); return (e && atoi(e) == 32) ? 32 : 16; }();
+  static const int b = [] { const char* e = getenv("MMST_FFN_WAVE_ROWS_BWD"); return (e && atoi(e) == 16) ? 16 : 32; }();
+  return bwd ? b : f;
 }
 
 int ffn_fwd_unfused(FfnBatch& b, hipStream_t stream) {
@@ -595,9 +599,9 @@ int ffn_bwd_unfused(FfnBatch& b, hipStream_t stream) {
 }
 
 // Workgroup shape of a fused launch: 8 waves of 16 rows; 10 waves when that brings a launch of more than 256
-// 128-row tiles down to one workgroup per CU; MMST_FFN_WAVE_ROWS=32 selects the 4-wave shape.
-int pick_waves(const FfnBatch& b) {
-  if (wave_rows() == 32) return 4;
+// 128-row tiles down to one workgroup per CU; or the 4-wave shape, see wave_rows().
+int pick_waves(const FfnBatch& b, bool bwd) {
+  if (wave_rows(bwd) == 32) return 4;
   int t128 = 0, t160 = 0;
   for (int i = 0; i < b.n; ++i) {
     t128 += (b.p[i].epi.Pn + 127) / 128;
@@ -621,7 +625,7 @@ void launch_bwd_shape(const FfnBatch& b, int total, bool split, hipStream_t stre
 
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
-  const int nw = pick_waves(b);
+  const int nw = pick_waves(b, false);
   int total = prepare(b, false, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
@@ -638,7 +642,7 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
 
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
-  const int nw = pick_waves(b);
+  const int nw = pick_waves(b, true);
   int total = prepare(b, true, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;

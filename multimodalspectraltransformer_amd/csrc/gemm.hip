@@ -1,10 +1,12 @@
 // Grouped bf16 MFMA GEMM for gfx950 with fused bias / ReLU / dropout / residual /
 // LayerNorm (forward and backward) / split-K atomic epilogues.  See gemm.h.
 //
-// Tile: 128 (P) x 128 (Q) x 64 (contraction), 256 threads = 4 waves.
-//   wave layout 2x2 (64x64 per wave) for the plain epilogues,
-//   wave layout 4x1 (32 P-rows x all 128 Q-columns per wave) for the LayerNorm
+// Tile: 128 (P) x 128 (Q) x 64 (contraction); NW = 8 waves (or 4: MMST_GEMM_WAVES=4).
+//   wave layout 4x2 (32x64 per wave; 2x2 of 64x64 with 4 waves) for the plain epilogues,
+//   wave layout 8x1 (16 P-rows x all 128 Q-columns per wave; 4x1 of 32 rows with 4 waves) for the LayerNorm
 //   epilogues, so a wave owns whole rows and row statistics need no LDS.
+// Eight waves at <= 128 registers give four waves per SIMD (two workgroups per CU): the dependent
+// barrier -> LDS read -> MFMA steps of one wave run in the shadow of the others.
 // MFMA: v_mfma_f32_16x16x32_bf16 with the WEIGHT side as the A operand and the token
 // side as the B operand: the accumulator then has the token row on the lane
 // (lane & 15) and 4 consecutive output columns in its 4 registers.  Two adjacent
@@ -15,15 +17,17 @@
 //   row-major operand      [128 index][64 c]  read with ds_read_b128
 //   contraction-major      [64 c][128 index]  read with ds_read_b64_tr_b16
 #include "gemm_tile.h"
+#include <cstdlib>
 
 namespace {
 
-template <int EPI, bool PT, bool QT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
+template <int EPI, bool PT, bool QT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch) {
   constexpr bool ROWEPI = (EPI == EPI_LN || EPI == EPI_LNBWD);
-  constexpr int MT = ROWEPI ? 2 : 4;
+  constexpr int MT = (ROWEPI ? 2 : 4) * 4 / NW;
   constexpr int NT = ROWEPI ? 8 : 4;
-  constexpr int SMEM = (EPI == EPI_ATOMIC) ? 4 * 32 * 65 * 4 : 2 * BP * BK * 2;  // images, or the atomic staging
+  constexpr int NL = 1024 / (NW * 64);   // 16-byte staging slots per thread and operand tile
+  constexpr int SMEM = (EPI == EPI_ATOMIC) ? NW * 32 * 65 * 4 : 2 * BP * BK * 2;  // images, or the atomic staging
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* Pimg = smem;
   unsigned char* Qimg = smem + BP * BK * 2;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   const int ptile = local % pr.ptiles;
   const int ks_id = local / pr.ptiles;
   const int p0 = ptile * BP, q0 = qt * BQ;
-  const int pw0 = ROWEPI ? wave * 32 : (wave >> 1) * 64;
+  const int pw0 = ROWEPI ? wave * 16 * MT : (wave >> 1) * 16 * MT;
   const int qw0 = ROWEPI ? 0 : (wave & 1) * 64;
 
   f32x4 acc[MT][NT];
@@ -105,31 +109,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   };
 
   if (kbeg < kend) {
-    uint4 rpA[4], rqA[4], rpB[4], rqB[4];
-    g2r<PT>(rpA, pr.P, pr.ldp, p0, pr.Pn, kbeg * BK, pr.K, tid);
-    g2r<QT>(rqA, pr.Q, pr.ldq, q0, pr.Qn, kbeg * BK, pr.K, tid);
+    uint4 rpA[NL], rqA[NL], rpB[NL], rqB[NL];
+    g2r<PT, NL>(rpA, pr.P, pr.ldp, p0, pr.Pn, kbeg * BK, pr.K, tid);
+    g2r<QT, NL>(rqA, pr.Q, pr.ldq, q0, pr.Qn, kbeg * BK, pr.K, tid);
     if (kbeg + 1 < kend) {
-      g2r<PT>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kbeg + 1) * BK, pr.K, tid);
-      g2r<QT>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kbeg + 1) * BK, pr.K, tid);
+      g2r<PT, NL>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kbeg + 1) * BK, pr.K, tid);
+      g2r<QT, NL>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kbeg + 1) * BK, pr.K, tid);
     }
     for (int kt = kbeg; kt < kend; kt += 2) {
       __syncthreads();
-      r2s<PT, false>(Pimg, rpA, tid);
-      r2s<QT, true>(Qimg, rqA, tid);
+      r2s<PT, false, NL>(Pimg, rpA, tid);
+      r2s<QT, true, NL>(Qimg, rqA, tid);
       __syncthreads();
       if (kt + 2 < kend) {
-        g2r<PT>(rpA, pr.P, pr.ldp, p0, pr.Pn, (kt + 2) * BK, pr.K, tid);
-        g2r<QT>(rqA, pr.Q, pr.ldq, q0, pr.Qn, (kt + 2) * BK, pr.K, tid);
+        g2r<PT, NL>(rpA, pr.P, pr.ldp, p0, pr.Pn, (kt + 2) * BK, pr.K, tid);
+        g2r<QT, NL>(rqA, pr.Q, pr.ldq, q0, pr.Qn, (kt + 2) * BK, pr.K, tid);
       }
       compute_tile();
       if (kt + 1 < kend) {
         __syncthreads();
-        r2s<PT, false>(Pimg, rpB, tid);
-        r2s<QT, true>(Qimg, rqB, tid);
+        r2s<PT, false, NL>(Pimg, rpB, tid);
+        r2s<QT, true, NL>(Qimg, rqB, tid);
         __syncthreads();
         if (kt + 3 < kend) {
-          g2r<PT>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kt + 3) * BK, pr.K, tid);
-          g2r<QT>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kt + 3) * BK, pr.K, tid);
+          g2r<PT, NL>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kt + 3) * BK, pr.K, tid);
+          g2r<QT, NL>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kt + 3) * BK, pr.K, tid);
         }
         compute_tile();
       }
@@ -187,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   if constexpr (EPI == EPI_ATOMIC) {
     // Split-K accumulation into the fp32 gradient.  Float atomics only run at full rate when one
     // wave-instruction covers 256 contiguous bytes, so each wave transposes its 64x64 sub-tile through
-    // LDS (two passes of 32 rows) and adds whole 64-float row segments.
+    // LDS (passes of 32 rows) and adds whole 64-float row segments.
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 65);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < MT / 2; ++half) {
       __syncthreads();
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
@@ -228,17 +232,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
   }
 
   if constexpr (EPI == EPI_LNBWD) {
-    if constexpr (ROWEPI) epi_lnbwd(acc, pr, p0, pw0, lane, wave, tid, smem);
+    if constexpr (ROWEPI) epi_lnbwd<NW>(acc, pr, p0, pw0, lane, wave, tid, smem);
   }
 }
 
-template <int EPI>
-int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
-  if (!pt && !qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, false>), dim3(grid), dim3(256), 0, s, b);
-  else if (!pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, true>), dim3(grid), dim3(256), 0, s, b);
-  else if (pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, true, true>), dim3(grid), dim3(256), 0, s, b);
+int gemm_waves(bool wgrad) {
+  static const int v = [] { const char* e = getenv("MMST_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  static const int w = [] { const char* e = getenv("MMST_GEMM_WAVES_WGRAD"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  return wgrad ? w : v;
+}
+
+template <int EPI, int NW>
+int dispatch_nw(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
+  if (!pt && !qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, false, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
+  else if (!pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, true, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
+  else if (pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, true, true, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
   else return MMST_ERR_ARG;
   return MMST_OK;
+}
+template <int EPI>
+int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
+  return gemm_waves(EPI == EPI_ATOMIC) == 4 ? dispatch_nw<EPI, 4>(b, pt, qt, grid, s) : dispatch_nw<EPI, 8>(b, pt, qt, grid, s);
 }
 
 }  // namespace

@@ -10,13 +10,13 @@ constexpr int BP = 128, BQ = 128, BK = 64;
 
 __device__ __forceinline__ int fsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-// ---- global -> registers (one 128x64 / 64x128 bf16 tile = 4 x 16 B per thread) ----
-template <bool T>
-__device__ __forceinline__ void g2r(uint4 (&r)[4], const bf16* __restrict__ base, int ld, int i0, int iN,
+// ---- global -> registers (one 128x64 / 64x128 bf16 tile = 1024 x 16 B over the workgroup's 1024/NL threads) ----
+template <bool T, int NL>
+__device__ __forceinline__ void g2r(uint4 (&r)[NL], const bf16* __restrict__ base, int ld, int i0, int iN,
                                     int c0, int cN, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
+  for (int i = 0; i < NL; ++i) {
+    int c = tid + (1024 / NL) * i;
     int gi, gc;
     size_t off;
     if (!T) {
@@ -36,11 +36,11 @@ __device__ __forceinline__ void g2r(uint4 (&r)[4], const bf16* __restrict__ base
 
 // ---- registers -> LDS image.  QSW selects the swizzle key of the row-major image:
 // the P side is read with natural rows (key row&7), the Q side with interleaved rows.
-template <bool T, bool QSW>
-__device__ __forceinline__ void r2s(unsigned char* img, const uint4 (&r)[4], int tid) {
+template <bool T, bool QSW, int NL>
+__device__ __forceinline__ void r2s(unsigned char* img, const uint4 (&r)[NL], int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
+  for (int i = 0; i < NL; ++i) {
+    int c = tid + (1024 / NL) * i;
     int off;
     if (!T) {
       int row = c >> 3, ch = c & 7;

@@ -65,8 +65,8 @@ def attn_keep_mask(seed, rowid, key, p):
     rs = mix32((np.uint64(seed) + rowid.astype(np.uint64) * np.uint64(0x9E3779B9)) & M)
     t = (rs + (key.astype(np.uint64) >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & M
     t ^= t >> np.uint64(16)
-    t = (t * np.uint64(0x7feb352d)) & M
-    t ^= t >> np.uint64(15)
+    t = ((t & np.uint64(0xFFFFFF)) * np.uint64(0x9E3779)) & M
+    t ^= t >> np.uint64(16)
     bits = np.where((key.astype(np.uint64) & np.uint64(1)) == 1, t >> np.uint64(16), t & np.uint64(0xFFFF))
     return bits >= thr
 
