@@ -33,7 +33,7 @@ class GemmProb(C.Structure):
 
 
 class GemmBatch(C.Structure):
-    _fields_ = [("n", C.c_int), ("p", GemmProb * GEMM_MAX_GROUPS)]
+    _fields_ = [("n", C.c_int), ("lds_pad", C.c_int), ("p", GemmProb * GEMM_MAX_GROUPS)]
 
 
 class AttnProb(C.Structure):

@@ -41,6 +41,8 @@ struct GemmProb {
 #define GEMM_MAX_GROUPS 16
 struct GemmBatch {
   int n;
+  int lds_pad = 0;   // extra (unused) dynamic LDS per workgroup in bytes: > 14 KiB keeps a split-K launch at one
+                     // workgroup per CU, so that kernels of another stream always find free registers next to it
   GemmProb p[GEMM_MAX_GROUPS];
 };
 

@@ -242,11 +242,18 @@ int gemm_waves(bool wgrad) {
   return wgrad ? w : v;
 }
 
+// Experiment switch: MMST_WGRAD_LDS_PAD=<bytes> pads EVERY split-K launch (see GemmBatch::lds_pad).
+int wgrad_lds_pad() {
+  static const int v = [] { const char* e = getenv("MMST_WGRAD_LDS_PAD"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 template <int EPI, int NW>
 int dispatch_nw(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
-  if (!pt && !qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, false, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
-  else if (!pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, true, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
-  else if (pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, true, true, NW>), dim3(grid), dim3(NW * 64), 0, s, b);
+  const int dyn = EPI == EPI_ATOMIC ? (b.lds_pad > wgrad_lds_pad() ? b.lds_pad : wgrad_lds_pad()) : 0;
+  if (!pt && !qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, false, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
+  else if (!pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
+  else if (pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, true, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
   else return MMST_ERR_ARG;
   return MMST_OK;
 }

@@ -176,12 +176,6 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
   auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
   const uint32_t thr = drop_threshold(pr.drop_p);
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
-  float gam[4][8], bet[4][8];
-#pragma unroll
-  for (int tp = 0; tp < 4; ++tp) {
-    load8f(gam[tp], pr.gamma + tp * 32 + 8 * q);
-    load8f(bet[tp], pr.beta + tp * 32 + 8 * q);
-  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
@@ -225,9 +219,11 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
       for (int tp = 0; tp < 4; ++tp) {
         const int n = tp * 32 + 8 * q;
         if (pr.Z) store8(pr.Z + (size_t)m * 128 + n, z[tp]);
-        float y[8];
+        float y[8], gam[8], bet[8];   // scale and shift are read where they are used (cache hits): 64 fewer live registers
+        load8f(gam, pr.gamma + n);
+        load8f(bet, pr.beta + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = (z[tp][e] - mean) * rstd * gam[tp][e] + bet[tp][e];
+        for (int e = 0; e < 8; ++e) y[e] = (z[tp][e] - mean) * rstd * gam[e] + bet[e];
         store8((bf16*)pr.C + crow(m) * pr.ldc + n, y);
       }
       if (q == 0 && pr.stats) { pr.stats[2 * (size_t)m] = mean; pr.stats[2 * (size_t)m + 1] = rstd; }

@@ -71,7 +71,7 @@ inline GemmProb dgrad(const void* dy, int M, int N, const void* w, int Kw, void*
 // so that every workgroup runs about the same number of 64-row contraction steps and the whole launch
 // has about ksplit_target() workgroups: small outputs then see a 10-20-way split (low atomic contention)
 // instead of one sized to fill the chip on their own.
-inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st) {
+inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st, int lds_pad = 0) {
   long work = 0;
   for (int i = 0; i < np; ++i) {
     long tiles = ((probs[i].Pn + 127) / 128) * (long)((probs[i].Qn + 127) / 128);
@@ -88,6 +88,7 @@ inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st) {
   for (int base = 0; base < np; base += GEMM_MAX_GROUPS) {
     GemmBatch gb;
     gb.n = np - base < GEMM_MAX_GROUPS ? np - base : GEMM_MAX_GROUPS;
+    gb.lds_pad = lds_pad;
     for (int i = 0; i < gb.n; ++i) gb.p[i] = probs[base + i];
     int rc = launch_gemm(gb, EPI_ATOMIC, true, true, st);
     if (rc) return rc;
@@ -543,7 +544,9 @@ int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts*
   probs[4] = wgrad(w->dkvc, ML, 2 * D, a->mem, D, g->w_cqkv + D * D, g->b_cqkv + D);
   probs[5] = wgrad(dzd1, M, D, a->attn1, D, g->w_o, g->b_o);
   probs[6] = wgrad(w->dqkv, M, 3 * D, a->x, D, g->w_qkv, g->b_qkv);
-  return launch_wgrads(probs, 7, (hipStream_t)stream_);
+  // One workgroup per CU: the small, register-heavy kernels of the decoder's data pass (the row epilogue of the
+  // split feed-forward block above all) run next to this launch and would otherwise wait for its grid to drain.
+  return launch_wgrads(probs, 7, (hipStream_t)stream_, 20000);
 }
 
 int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
