@@ -129,9 +129,17 @@ def main():
     tap = rank == 0 and not args.no_tap
     if tap:
         L.check(lib.mmst_tap_config(L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
+    gaps = os.environ.get("MMST_BENCH_GAPS") == "1"   # diagnostic: GPU idle time between consecutive steps
+    evs = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if gaps:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         out = tm.training_step(batches[i % len(batches)], i)
+        if gaps:
+            e1.record()
+            evs.append((e0, e1))
     t_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (the GPU may still be running)
     sync()
     dt = time.perf_counter() - t0
@@ -162,6 +170,9 @@ def main():
                           "global_batch": world * args.batch, "parallelism": f"dp{world}"},
                "final_loss": loss,
                "model_tflops": mols * FLOP_PER_MOL_STEP / dt / 1e12}
+        if gaps:
+            res["gpu_idle_between_steps_ms"] = sum(evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(len(evs) - 1)) / (len(evs) - 1)
+            res["gpu_ms_inside_step"] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
         if tap:
             ms = C.c_float(0)
             cnt = C.c_int(0)

@@ -46,6 +46,8 @@ struct GemmBatch {
   GemmProb p[GEMM_MAX_GROUPS];
 };
 
+int gemm_waves_for(int epi);   // waves per workgroup of the kernel variant that serves this epilogue
+
 // Diagnostic tap (bench.py): HIP events around every launch of ONE kernel variant, on the launch stream.
 struct GemmTap {
   int epi, pt, qt;       // variant to time; epi < 0 = off

@@ -264,6 +264,8 @@ int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
 
 }  // namespace
 
+int gemm_waves_for(int epi) { return gemm_waves(epi == EPI_ATOMIC); }
+
 GemmTap g_gemm_tap = {-1, 0, 0, 0, 0, nullptr, nullptr, 0.0, 0.0};
 
 int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {

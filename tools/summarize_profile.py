@@ -15,7 +15,7 @@ import sys
 
 def load(pat):
     fs = glob.glob(pat)
-    return list(csv.DictReader(open(fs[0]))) if fs else []
+    return list(csv.DictReader(open(max(fs, key=os.path.getmtime)))) if fs else []   # newest run of that tag
 
 
 def short(n):
