@@ -1,7 +1,7 @@
-"""Inference drivers: encoder half, greedy / multinomial decode.
+"""Inference drivers: encoder half, greedy / multinomial decode, beam search.
 
 Counterparts of utils_MMT/validate_generate_MMT_v15_4.py (run_model :95, greedy_sequence :723,
-multinomial_sequence :841) and of _generate_sequences (models_MMT_v15_4.py:1222-1297).  The decode
+multinomial_sequence :841, beam_search :1056) and of _generate_sequences (models_MMT_v15_4.py:1222-1297).  The decode
 loop keeps the reference's outputs (stop when every next token is <PAD>) but not its cost: the reference
 re-runs the decoder on the whole prefix for every token; here each step computes only the new position
 (mmst_decoder_layer_step: self-attention keys/values cached per layer, cross-attention keys/values of the
@@ -38,12 +38,17 @@ D = 128
 
 class _StepState:
     """Per-plan buffers and prebuilt structs of the cached decode: one Q|K|V cache per decoder layer, two
-    ping-pong row buffers, shared scratch."""
+    ping-pong row buffers, shared scratch.  rep > 1 (beam search): every molecule owns `rep` consecutive
+    sequences, which read copies of its memory keys/values and key bias (refresh_memory)."""
 
-    def __init__(self, model, pl):
+    def __init__(self, model, pl, rep=1):
         from . import ops
-        dev, B, cap = pl.cv.buf[torch.bfloat16].device, pl.B, pl.cap_T
+        dev, B, cap = pl.cv.buf[torch.bfloat16].device, pl.B * rep, pl.cap_T
         ndl = model.num_decoder_layers
+        self.rep, self.B = rep, B
+        if rep > 1:
+            self.kvc = [torch.empty(B, pl.Lmem, 2 * D, dtype=torch.bfloat16, device=dev) for _ in range(ndl)]
+            self.mem_bias = torch.empty(B, pl.Lmem, dtype=torch.float32, device=dev)
         bf = dict(dtype=torch.bfloat16, device=dev)
         self.cache = [torch.zeros(B, cap, 3 * D, **bf) for _ in range(ndl)]
         self.rows = [torch.zeros(B, D, **bf) for _ in range(2)]
@@ -57,8 +62,8 @@ class _StepState:
             s = L.DecStep()
             s.x, s.y = self.rows[l % 2].data_ptr(), self.rows[(l + 1) % 2].data_ptr()
             s.qkv_cache = self.cache[l].data_ptr()
-            s.kvc = _P(pl.dec_acts[l]["kvc"])
-            s.mem_bias = _P(pl.kbias_glob)
+            s.kvc = _P(pl.dec_acts[l]["kvc"]) if rep == 1 else self.kvc[l].data_ptr()
+            s.mem_bias = _P(pl.kbias_glob) if rep == 1 else self.mem_bias.data_ptr()
             for f in ("attn", "x1", "qc", "x2", "h", "lse"):
                 setattr(s, f, getattr(self, f).data_ptr())
             s.ffn_ws = self.ws.data_ptr()
@@ -67,6 +72,14 @@ class _StepState:
         self.out = self.rows[ndl % 2]
         self.ops = ops
         self.graphs = {}   # (position, temperature) -> captured token step
+
+    def refresh_memory(self, model, pl):
+        """Copies of the projected memory keys/values and of the key bias for each of a molecule's sequences."""
+        for l in range(model.num_decoder_layers):
+            src = pl.cv.view(pl.dec_acts[l]["kvc"], pl.B, pl.Lmem, 2 * D)
+            self.kvc[l].view(pl.B, self.rep, pl.Lmem, 2 * D).copy_(src.unsqueeze(1).expand(-1, self.rep, -1, -1))
+        kb = pl.cv.view(pl.kbias_glob, pl.B, pl.Lmem)
+        self.mem_bias.view(pl.B, self.rep, pl.Lmem).copy_(kb.unsqueeze(1).expand(-1, self.rep, -1))
 
 
 def _cross_kv(model, pl):
@@ -217,6 +230,98 @@ def generate_sequences(model, pl, config, stoi, itos, temperature=1):
     if itos:
         smiles, conf = hf.tensor_to_smiles_and_prob_2(toks[1:], probs, itos)
     return toks, smiles, conf
+
+
+def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
+    """validate_generate_MMT_v15_4.py:1056-1094 with the reference's bookkeeping (:995-1053: de-duplication,
+    finished beams carried over, score = product of the ranking probabilities, stable sort) but not its cost.
+    The reference runs the decoder once per molecule, beam and step on the whole prefix; here all
+    molecules x beams advance together by one cached position per step (mmst_decoder_layer_step on B * beam_size
+    sequences), the top-k of the softmax is taken on the device, and only those k probabilities and indices per
+    sequence go to the host, where the beams are re-ranked exactly like the reference does.  A beam inherits the
+    key/value cache of the sequence it extends (one gather per layer and step).
+    Returns beams[i] = list of (score, token list incl. <SOS>, probability list), best first."""
+    pl = _plan_for(model, memory)
+    eng, ar = model._engine, model._engine.arena
+    B, W = pl.B, int(beam_size)
+    sos, eos = stoi["<SOS>"], stoi["<EOS>"]
+    gen_len = int(config.gen_len)
+    if gen_len > pl.cap_T:
+        raise L.MMSTError(f"gen_len {gen_len} exceeds the plan's capacity of {pl.cap_T} target positions")
+    lib, st = L.lib(), L.stream_ptr
+    key = "_beam_state_%d" % W
+    stt = getattr(pl, key, None)
+    if stt is None:
+        stt = _StepState(model, pl, rep=W)
+        setattr(pl, key, stt)
+    was_training = model.training
+    model.eval()
+    _cross_kv(model, pl)
+    stt.refresh_memory(model, pl)
+    dev = stt.logits.device
+    emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
+    tok = torch.zeros(B * W, dtype=torch.long, device=dev)
+    beams = [[(1, [sos], [])] for _ in range(B)]
+    for idx in range(gen_len):
+        # slots of this step: the distinct, unfinished beams of every molecule (the reference's `seen` filter)
+        slots = []            # per molecule: list of (slot or None for carried-over beams, beam)
+        toks = [0] * (B * W)
+        for i in range(B):
+            seen, row = set(), []
+            for beam in beams[i]:
+                t = tuple(beam[1])
+                if t in seen:
+                    continue
+                seen.add(t)
+                if beam[1][-1] == eos:
+                    row.append((None, beam))
+                else:
+                    slot = i * W + sum(1 for s_, _ in row if s_ is not None)
+                    toks[slot] = beam[1][-1]
+                    row.append((slot, beam))
+            slots.append(row)
+        tok.copy_(torch.tensor(toks, dtype=torch.long), non_blocking=False)
+        L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok.data_ptr()), B * W, C.c_void_p(emb), C.c_void_p(pe + 4 * D * idx),
+                                       C.c_void_p(stt.rows[0].data_ptr()), B * W, 1, C.c_float(0.0), C.c_uint32(0), st()),
+                "mmst_trg_embed_fwd")
+        for l, s in enumerate(stt.steps):
+            s.pos = idx
+            L.check(lib.mmst_decoder_layer_step(C.byref(pl.dec_p[l]), C.byref(s), 16, st()), "mmst_decoder_layer_step")
+        stt.ops.gemm([dict(P=stt.out, Q=ar.pb("fc_out.weight"), C=stt.logits, bias=ar.p32("fc_out.bias"),
+                           ldp=D, ldq=D, ldc=VPAD, Pn=B * W, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
+        probs = torch.softmax(stt.logits[:, :model.out_size], dim=1)      # :1038, no temperature
+        top_p, top_i = torch.topk(probs, W, dim=1)
+        top_p, top_i = top_p.cpu().tolist(), top_i.cpu().tolist()
+        parent = list(range(B * W))
+        for i in range(B):
+            new_beam, seen = [], set()
+            for slot, (score, sequence, prob_sequence) in slots[i]:
+                seen.add(tuple(sequence))
+                if slot is None:
+                    new_beam.append((score, sequence, prob_sequence, None))
+                    continue
+                for k in range(W):
+                    new_sequence = sequence + [top_i[slot][k]]
+                    t = tuple(new_sequence)
+                    if t in seen:
+                        continue
+                    seen.add(t)
+                    new_beam.append((score * top_p[slot][k], new_sequence, prob_sequence + [top_p[slot][k]], slot))
+            new_beam.sort(key=lambda x: x[0], reverse=True)
+            new_beam = new_beam[:W]
+            beams[i] = [(b[0], b[1], b[2]) for b in new_beam]
+            # next step's slot order = order of the unfinished beams in the new list (duplicates cannot occur here)
+            nslot = i * W
+            for b in new_beam:
+                if b[1][-1] != eos:
+                    parent[nslot] = b[3]
+                    nslot += 1
+        if idx + 1 < gen_len and parent != list(range(B * W)):
+            pidx = torch.tensor(parent, dtype=torch.long, device=dev)
+            for c in stt.cache:
+                c[:, :idx + 1] = c.index_select(0, pidx)[:, :idx + 1]
+    model.train(was_training)
+    return beams
 
 
 def _plan_for(model, memory):

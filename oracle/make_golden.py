@@ -179,6 +179,39 @@ def greedy_case(M, vg, name, mode, nl, B, seed, wseed, gain):
     print(name, 'steps', toks.shape, 'min margin', float(margins.min()), smiles[:2])
 
 
+def beam_case(M, vg, name, mode, nl, B, seed, wseed, gain, beam_size, gen_len):
+    """Reference beam search (validate_generate_MMT_v15_4.py:1056) on seeded weights/inputs; the oracle must
+    reproduce its sequences exactly and its scores to fp32 rounding."""
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.1, gen_len=gen_len)
+    model = M.MultimodalTransformer(cfg)
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    model.load_state_dict(O.make_state_dict(ocfg, wseed, logit_gain=gain))
+    model.eval()
+    b = O.synthetic_batch(B, seed, mode)
+    b['src_HSQC_'] = b['src_HSQC']
+    b['src_COSY_'] = b['src_COSY']
+    memory, mask, trg, fp, _, _ = vg.run_model(model, b, cfg)
+    stoi = json.load(open(f'{REF}/stoi.json'))
+    beams = vg.beam_search(model, stoi, memory, mask, cfg, beam_size)
+    sd = {k: v for k, v in model.state_dict().items()}
+    obeams, margins = O.beam_search(sd, ocfg, memory, mask, beam_size, gen_len, stoi["<SOS>"], stoi["<EOS>"])
+    seqs = np.zeros((B, beam_size, gen_len + 1), np.int64)
+    lens = np.zeros((B, beam_size), np.int64)
+    scores = np.zeros((B, beam_size), np.float64)
+    for i in range(B):
+        assert len(beams[i]) == len(obeams[i])
+        for j, ((sc, seq, pr), (osc, oseq, opr)) in enumerate(zip(beams[i], obeams[i])):
+            assert seq == oseq, f"oracle beam differs from reference: molecule {i} beam {j}"
+            assert abs(sc - osc) <= 1e-4 * abs(sc), (sc, osc)
+            seqs[i, j, :len(seq)] = seq
+            lens[i, j] = len(seq)
+            scores[i, j] = sc
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), seqs=seqs, lens=lens, scores=scores,
+                        margins=np.array(margins), seed=np.int64(seed), wseed=np.int64(wseed), B=np.int64(B),
+                        nl=np.int64(nl), gain=np.float64(gain), beam_size=np.int64(beam_size), gen_len=np.int64(gen_len))
+    print(name, 'margins', margins, 'best', seqs[0, 0], scores[0])
+
+
 def text_case(hf, dl):
     stoi = json.load(open(f'{REF}/stoi.json'))
     itos = json.load(open(f'{REF}/itos.json'))
@@ -287,6 +320,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'data':      # only the data-path fixtures
         data_case(dl)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'beam':      # only the beam-search fixture
+        beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)
+        return
     forward_case(M, 'fwd_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 3, seed=11, wseed=101, steps=2)
     forward_case(M, 'fwd_c1_L2', '1H', 2, 4, seed=12, wseed=102)
     forward_case(M, 'fwd_all_L1', '1H_13C_HSQC_COSY_IR_MF_MW', 1, 2, seed=13, wseed=103)
@@ -295,6 +331,7 @@ def main():
     forward_case(M, 'fwd_c2_L6', '1H_HSQC_COSY_IR_MF_MW', 6, 2, seed=16, wseed=106, with_grads=False)
     greedy_case(M, vg, 'greedy_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 8, seed=21, wseed=201, gain=1.0)
     greedy_case(M, vg, 'greedy_c1_L2', '1H', 2, 4, seed=22, wseed=202, gain=1.0)
+    beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)
     text_case(hf, dl)
     data_case(dl)
 

@@ -407,6 +407,56 @@ def greedy_sequence(sd, cfg, memory, mask, sos=3, temperature=1.0, early_stop=Tr
 
 
 # ----------------------------------------------------------------------------
+# beam search (validate_generate_MMT_v15_4.py:995-1094)
+# ----------------------------------------------------------------------------
+
+def beam_search_step(sd, cfg, beam, memory, mask, beam_size, eos=2):
+    """One step for one molecule (:995-1053).  beam = list of (score, token list, probability list).
+    Also returns the decision margins of the step: the smallest relative score gap between neighbours in the
+    sorted candidate list down to the first dropped candidate (a reduced-precision run is only comparable with
+    this one while those gaps are large)."""
+    new_beam, seen = [], set()
+    for score, sequence, prob_sequence in beam:
+        key = tuple(sequence)
+        if key in seen:                       # :1015
+            continue
+        seen.add(key)
+        if sequence[-1] == eos:               # :1019 finished beams are carried over unchanged
+            new_beam.append((score, sequence, prob_sequence))
+            continue
+        trg = torch.tensor(sequence, dtype=torch.long).unsqueeze(1)
+        logits = decode_logits(sd, cfg, trg, memory, mask)
+        probs = torch.softmax(logits[-1], dim=-1)          # :1038 no temperature on the ranking distribution
+        top_probs, top_idx = torch.topk(probs, beam_size, dim=-1)
+        for i in range(beam_size):
+            new_sequence = sequence + [int(top_idx[0, i])]
+            if tuple(new_sequence) in seen:   # :1046
+                continue
+            seen.add(tuple(new_sequence))
+            p = float(top_probs[0, i])
+            new_beam.append((score * p, new_sequence, prob_sequence + [p]))
+    new_beam.sort(key=lambda x: x[0], reverse=True)        # :1052 stable sort, ties keep generation order
+    margin = float("inf")
+    for a, b in zip(new_beam[:beam_size], new_beam[1:beam_size + 1]):
+        margin = min(margin, (a[0] - b[0]) / max(a[0], 1e-300))
+    return new_beam[:beam_size], margin
+
+
+def beam_search(sd, cfg, memory, mask, beam_size, gen_len, sos=3, eos=2):
+    """:1056-1094.  Returns (beams, margins): beams[i] = list of (score, tokens incl. <SOS>, probabilities) for
+    molecule i, best first; margins[i] = smallest decision margin over all steps of molecule i."""
+    N = memory.shape[1]
+    beams = [[(1, [sos], [])] for _ in range(N)]
+    margins = [float("inf")] * N
+    for _ in range(gen_len):
+        for i in range(N):
+            mask_i = mask[i:i + 1] if mask is not None else None
+            beams[i], m = beam_search_step(sd, cfg, beams[i], memory[:, i:i + 1, :], mask_i, beam_size, eos)
+            margins[i] = min(margins[i], m)
+    return beams, margins
+
+
+# ----------------------------------------------------------------------------
 # tokenizer / detokenizer / collate helpers
 # ----------------------------------------------------------------------------
 

@@ -99,6 +99,24 @@ def test_greedy_tokens_identical(name, mode):
     assert O.tensor_to_smiles(toks, itos) == [str(s) for s in g["smiles"]]
 
 
+def test_beam_search_identical():
+    """Oracle beam search against the reference's beams (validate_generate_MMT_v15_4.py:1056)."""
+    g = load_golden("beam_c2_L2")
+    mode, nl = "1H_HSQC_COSY_IR_MF_MW", int(g["nl"])
+    cfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    sd = O.make_state_dict(cfg, int(g["wseed"]), logit_gain=float(g["gain"]))
+    batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), mode)
+    with torch.no_grad():
+        memory, _, mask, fp = O.forward(sd, cfg, batch, None)
+        beams, margins = O.beam_search(sd, cfg, memory, mask, int(g["beam_size"]), int(g["gen_len"]))
+    for i, beam in enumerate(beams):
+        for j, (score, seq, probs) in enumerate(beam):
+            assert seq == g["seqs"][i, j, :g["lens"][i, j]].tolist(), (i, j)
+            assert abs(score - g["scores"][i, j]) <= 1e-4 * g["scores"][i, j]
+            assert len(probs) == len(seq) - 1
+    np.testing.assert_allclose(margins, g["margins"], rtol=1e-2, atol=1e-5)
+
+
 def test_tokenizer_and_padding():
     t = json.load(open(os.path.join(GOLDEN, "text.json")))
     stoi = json.load(open(os.path.join(GOLDEN, "stoi.json")))
