@@ -227,6 +227,34 @@ int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, 
  * weights the backward pass reads in step with the bf16 weight copy after an optimizer step. */
 int mmst_transpose_bf16(const void* src, void* dst, int n, const uint32_t* offsets, int rows, int cols, void* stream);
 
+/* ---- CLIP contrastive head on the encoder half (utils_MMT/models_CLIP_v15_4.py), all fp32 ---- */
+
+/* C[M][N] = alpha * sum_k A(i,k) B(k,j) + beta * C + bias[j], with A(i,k) = A[i*sai + k*sak] and
+ * B(k,j) = B[k*sbk + j*sbj]: by choice of strides the nn.Linear forward of ProjectionHead (:413-415, :420-422),
+ * its dX / dW products, and the B x B similarity products of CLIPModel.forward (:293-295) and their backward. */
+int mmst_sgemm(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, int ldc,
+               const float* bias, int M, int N, int K, float alpha, float beta, void* stream);
+/* nn.GELU() (:414, :421), exact erf form; backward ADDS dy * gelu'(x) to dx. */
+int mmst_gelu_fwd(const float* x, float* y, long n, void* stream);
+int mmst_gelu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+/* Tail of ProjectionHead.forward (:423-425): out = LayerNorm(dropout(f) + projected), rows x P (P <= 1024);
+ * keeps the normalised rows and 1/std for the backward, which returns df (dropout applied), dproj (the
+ * residual branch) and ADDS dgamma / dbeta. */
+int mmst_head_out_fwd(const float* f, const float* projected, const float* gamma, const float* beta, float* out,
+                      float* xhat, float* rstd, int rows, int P, float drop_p, uint32_t seed, void* stream);
+int mmst_head_out_bwd(const float* dout, const float* xhat, const float* rstd, const float* gamma, float* df, float* dproj,
+                      float* dgamma, float* dbeta, int rows, int P, float drop_p, uint32_t seed, void* stream);
+/* Symmetric soft-target cross entropy (:296-302 with cross_entropy :390-396) and its gradient: logits [B][B],
+ * Z = (MT_similarity + CB_similarity) / 2 * temperature [B][B]; targets = softmax(Z) are NOT detached in the
+ * reference, so dZ is returned next to dlogits (both for L = mean of the per-sample losses).  ws: scratch of
+ * 5*B*B + 3*B floats.  losses [B]; the mean is ADDED to *loss_mean. */
+int mmst_clip_loss(const float* logits, const float* Z, int B, float* ws, float* losses, float* loss_mean, float* dlogits,
+                   float* dZ, void* stream);
+/* out = X + X^T for a [B][B] matrix (gradient of X X^T products). */
+int mmst_symmetrize(const float* X, float* out, int B, void* stream);
+/* backward of torch.mean(memory, dim=0) (models_MMT_v15_4.py:946): dmem[b][l][:] = dmean[b][:] / L, bf16 out */
+int mmst_seq_mean_bwd(const float* dmean, void* dmem, int B, int L, void* stream);
+
 int mmst_version(void);
 
 #ifdef __cplusplus

@@ -383,3 +383,32 @@ def iter_batches(dataset, batch_size, rank=0, world=1, shuffle=False, seed=0, ma
                 if k in batch:
                     batch[k] = batch[k].float()
         yield batch
+
+
+def weight_sorted_batches(mol_weights, batch_size, drop_last=False, window_size=None, rng=None):
+    """Batches of indices of similar molecular weight for contrastive training: WeightSortedBatchSampler of
+    clip_functions_v15_4.py:117-152.  Indices are sorted by weight (stable, like DataFrame.sort_values), cut into
+    windows of `window_size` (default max(batch_size, 4)) that are shuffled one by one with `rng.shuffle`
+    (the reference uses the global `random` module: pass `random` to reproduce a seeded run of it), and a batch
+    is emitted whenever exactly batch_size indices have been collected; leftovers form a last batch unless
+    drop_last.  Like the reference, a window size that does not divide batch_size makes the collected count skip
+    over batch_size, and then everything ends up in the final batch."""
+    import random as _random
+    rng = rng or _random
+    window_size = window_size if window_size is not None else max(batch_size, 4)
+    order = sorted(range(len(mol_weights)), key=lambda i: mol_weights[i])
+    batch, window = [], []
+    for idx in order:
+        window.append(idx)
+        if len(window) == window_size:
+            rng.shuffle(window)
+            batch.extend(window)
+            window = []
+            if len(batch) == batch_size:
+                yield batch
+                batch = []
+    if window:
+        rng.shuffle(window)
+        batch.extend(window)
+    if not drop_last and batch:
+        yield batch

@@ -622,8 +622,9 @@ class Engine:
         return pl.cv.view(pl.loss, 1)
 
     # ------------------------------------------------------------------
-    def backward(self, pl, train, on_segment=None):
+    def backward(self, pl, train, on_segment=None, skip_decoder=False):
         """Backward of decode() + encode() from pl.dlogits; accumulates into the flat gradient buffer.
+        skip_decoder=True starts at the encoder memory instead: the caller has filled pl.dmem (the CLIP head).
 
         Two streams: the critical path (activation gradients) runs on the current stream; each layer's
         parameter gradients (one grouped split-K launch) run on a second stream as soon as that layer's
@@ -649,39 +650,40 @@ class Engine:
             ev.record(main)
             ws.wait_event(ev)
 
-        # vocabulary projection
-        last = pl.dec_acts[ndl - 1]
-        sc = pl.dec_bwd[ndl - 1]
-        ops.gemm([dict(P=_P(pl.dlogits), Q=ar.pb("fc_out.weight"), C=_P(sc["dz"]),
-                       C2=_P(sc["dzd"]) if p_drop > 0 else None, Z=_P(last["z3"]), stats=_P(last["st3"]),
-                       gamma=ar.p32(f"decoder.layers.{ndl - 1}.norm3.weight"),
-                       dgamma=ar.g32(f"decoder.layers.{ndl - 1}.norm3.weight"),
-                       dbeta=ar.g32(f"decoder.layers.{ndl - 1}.norm3.bias"),
-                       ldp=VPAD, ldq=D, ldc=D, Pn=M, Qn=D, K=VPAD, drop_p=p_drop,
-                       seed=(self.layer_seed(64 + ndl - 1) + 5) & 0xFFFFFFFF)], L.EPI_LNBWD, qt=True)
-        with torch.cuda.stream(ws):
-            ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
-                           ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(16, M // 256)))],
-                     L.EPI_ATOMIC, pt=True, qt=True)
-        for l in reversed(range(ndl)):
-            w = pl.dec_w[l]
-            w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
-            w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
-            L.check(lib.mmst_decoder_layer_bwd_data(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
-                                                    C.byref(w), 16, C.c_float(p_drop),
-                                                    C.c_uint32(self.layer_seed(64 + l)), st),
-                    "mmst_decoder_layer_bwd_data")
+        if not skip_decoder:
+            # vocabulary projection
+            last = pl.dec_acts[ndl - 1]
+            sc = pl.dec_bwd[ndl - 1]
+            ops.gemm([dict(P=_P(pl.dlogits), Q=ar.pb("fc_out.weight"), C=_P(sc["dz"]),
+                           C2=_P(sc["dzd"]) if p_drop > 0 else None, Z=_P(last["z3"]), stats=_P(last["st3"]),
+                           gamma=ar.p32(f"decoder.layers.{ndl - 1}.norm3.weight"),
+                           dgamma=ar.g32(f"decoder.layers.{ndl - 1}.norm3.weight"),
+                           dbeta=ar.g32(f"decoder.layers.{ndl - 1}.norm3.bias"),
+                           ldp=VPAD, ldq=D, ldc=D, Pn=M, Qn=D, K=VPAD, drop_p=p_drop,
+                           seed=(self.layer_seed(64 + ndl - 1) + 5) & 0xFFFFFFFF)], L.EPI_LNBWD, qt=True)
+            with torch.cuda.stream(ws):
+                ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
+                               ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(16, M // 256)))],
+                         L.EPI_ATOMIC, pt=True, qt=True)
+            for l in reversed(range(ndl)):
+                w = pl.dec_w[l]
+                w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
+                w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
+                L.check(lib.mmst_decoder_layer_bwd_data(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
+                                                        C.byref(w), 16, C.c_float(p_drop),
+                                                        C.c_uint32(self.layer_seed(64 + l)), st),
+                        "mmst_decoder_layer_bwd_data")
+                weights_after_data()
+                L.check(lib.mmst_decoder_layer_bwd_weights(C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]), C.byref(w),
+                                                           C.c_float(p_drop), wst), "mmst_decoder_layer_bwd_weights")
+            # target-embedding gradients only feed parameters: off the critical path
             weights_after_data()
-            L.check(lib.mmst_decoder_layer_bwd_weights(C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]), C.byref(w),
-                                                       C.c_float(p_drop), wst), "mmst_decoder_layer_bwd_weights")
-        # target-embedding gradients only feed parameters: off the critical path
-        weights_after_data()
-        L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
-                                       C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
-                                       B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
-                                       wst), "mmst_trg_embed_bwd")
-        if on_segment:
-            on_segment("decoder")
+            L.check(lib.mmst_trg_embed_bwd(C.c_void_p(_P(pl.tok)), B, C.c_void_p(_P(pl.dtrg)),
+                                           C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
+                                           B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
+                                           wst), "mmst_trg_embed_bwd")
+            if on_segment:
+                on_segment("decoder")
         # cross encoder
         sc = pl.cross_bwd[nl - 1]
         lastc = pl.cross_acts[nl - 1]

@@ -212,6 +212,70 @@ def beam_case(M, vg, name, mode, nl, B, seed, wseed, gain, beam_size, gen_len):
     print(name, 'margins', margins, 'best', seqs[0, 0], scores[0])
 
 
+def clip_case(M, name, mode, nl, B, seed, wseed, hseed):
+    """Reference CLIPModel.forward (models_CLIP_v15_4.py:243-302) in eval mode with the ChemBERTa branch replaced
+    by given features (its weights are not in the repository): loss, per-sample losses and gradients of the
+    projection heads, of fp1 and of a few encoder tensors."""
+    import utils_MMT.models_CLIP_v15_4 as CL
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.1)
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    mt = M.MultimodalTransformer(cfg)
+    sd = O.make_state_dict(ocfg, wseed)
+    mt.load_state_dict(sd)
+    head = O.make_clip_head_state_dict(hseed)
+    b = O.synthetic_batch(B, seed, mode)
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    cb_feat = torch.from_numpy(rng.standard_normal((B, O.CLIP_DIMS["CB_embedding"])).astype(np.float32))
+
+    class GivenFeatures(torch.nn.Module):          # stands where ChembertaFingerprint would be called (:277)
+        def forward(self, ids, mask):
+            return None, cb_feat
+
+    def tokenizer(smiles, return_tensors='pt', padding=True):
+        return {'input_ids': torch.zeros(len(smiles), 1, dtype=torch.long),
+                'attention_mask': torch.ones(len(smiles), 1, dtype=torch.long)}
+
+    itos = json.load(open(f'{REF}/itos.json'))
+    clip = CL.CLIPModel(GivenFeatures(), mt, tokenizer, itos, cfg)
+    clip.load_state_dict({**head, **{'MT_model.' + k: v for k, v in sd.items()}})
+    clip.eval()
+    loss, losses = clip({k: v.clone() for k, v in b.items()})
+    loss.backward()
+    out = dict(loss=np.float64(loss.item()), losses=np_(losses.detach()), seed=np.int64(seed), wseed=np.int64(wseed),
+               hseed=np.int64(hseed), B=np.int64(B), nl=np.int64(nl))
+    for k, p in clip.named_parameters():
+        if k.startswith(('CB_projection.', 'MT_projection.')) or k in (
+                'MT_model.fp1.weight', 'MT_model.fp1.bias', 'MT_model.encoder_cross.layers.0.linear1.weight',
+                'MT_model.encoder_1H.layers.0.self_attn.in_proj_weight',
+                'MT_model.linear_spec_embedding_HSQC.point_embedding_layer_HSQC.fc_HSQC.weight'):
+            out['grad/' + k] = digest(p.grad)
+    # the oracle restatement must agree before the fixture is written
+    ohead = {k: v.clone().requires_grad_(True) for k, v in head.items()}
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ol, olosses = O.clip_forward(osd, ohead, ocfg, b, cb_feat, float(cfg.CLIP_temperature))
+    ol.backward()
+    assert abs(float(ol) - float(loss)) < 1e-5 * max(1.0, abs(float(loss))), (float(ol), float(loss))
+    g1 = dict(clip.named_parameters())['MT_projection.fc.weight'].grad
+    g2 = ohead['MT_projection.fc.weight'].grad
+    err = float((g2 - g1).abs().max() / g1.abs().max())
+    assert err < 1e-3, err
+    # MW-sorted batch sampler of the CLIP training loop (clip_functions_v15_4.py:117-152), seeded global RNG
+    import random
+    import pandas as pd
+    import utils_MMT.clip_functions_v15_4 as cf
+    mw = np.round(np.random.Generator(np.random.PCG64(7)).uniform(150, 500, 50), 1)
+
+    class _DS:
+        ref_data = pd.DataFrame({"MW": mw})
+    for bs, ws, dl_ in ((8, None, False), (8, 4, True), (6, 4, False)):
+        random.seed(5)
+        batches = list(cf.WeightSortedBatchSampler(_DS(), bs, dl_, ws))
+        out[f'sampler/{bs}_{ws}_{int(dl_)}'] = np.array([b + [-1] * (64 - len(b)) for b in batches], np.int64)
+    out['sampler_mw'] = mw
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+    print(name, 'loss', float(loss), 'losses', np_(losses.detach())[:4])
+
+
 def text_case(hf, dl):
     stoi = json.load(open(f'{REF}/stoi.json'))
     itos = json.load(open(f'{REF}/itos.json'))
@@ -320,6 +384,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'data':      # only the data-path fixtures
         data_case(dl)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'clip':      # only the CLIP-head fixture
+        clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'beam':      # only the beam-search fixture
         beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)
         return
@@ -332,6 +399,7 @@ def main():
     greedy_case(M, vg, 'greedy_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 8, seed=21, wseed=201, gain=1.0)
     greedy_case(M, vg, 'greedy_c1_L2', '1H', 2, 4, seed=22, wseed=202, gain=1.0)
     beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)
+    clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
     text_case(hf, dl)
     data_case(dl)
 

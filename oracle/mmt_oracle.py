@@ -407,6 +407,58 @@ def greedy_sequence(sd, cfg, memory, mask, sos=3, temperature=1.0, early_stop=Tr
 
 
 # ----------------------------------------------------------------------------
+# CLIP head on the encoder half (models_CLIP_v15_4.py:224-302, 390-426).  The ChemBERTa branch needs weights
+# that are not in the repository: its output features are an INPUT here.
+# ----------------------------------------------------------------------------
+
+CLIP_DIMS = dict(CB_embedding=1024, MT_embedding=512, projection_dim=512)   # config_V8.json
+
+
+def make_clip_head_state_dict(seed, dims=CLIP_DIMS):
+    """Seeded weights of CLIPModel.CB_projection / MT_projection (keys as in the reference's state_dict)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, e in (("CB_projection.", dims["CB_embedding"]), ("MT_projection.", dims["MT_embedding"])):
+        p = dims["projection_dim"]
+        for key, shape, fan in (("projection.weight", (p, e), e), ("projection.bias", (p,), e),
+                                ("fc.weight", (p, p), p), ("fc.bias", (p,), p)):
+            b = 1.0 / math.sqrt(fan)
+            sd[name + key] = torch.from_numpy(rng.uniform(-b, b, size=shape).astype(np.float32))
+        sd[name + "layer_norm.weight"] = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(p)).astype(np.float32))
+        sd[name + "layer_norm.bias"] = torch.from_numpy((0.1 * rng.standard_normal(p)).astype(np.float32))
+    return sd
+
+
+def projection_head(x, sd, pre):
+    """ProjectionHead.forward (:419-426) with dropout off: LN(fc(gelu(proj(x))) + proj(x)), exact (erf) GELU."""
+    projected = linear(x, sd[pre + "projection.weight"], sd[pre + "projection.bias"])
+    h = 0.5 * projected * (1.0 + torch.erf(projected / math.sqrt(2.0)))
+    h = linear(h, sd[pre + "fc.weight"], sd[pre + "fc.bias"])
+    return layer_norm(h + projected, sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
+
+
+def clip_loss(CB_emb, MT_emb, temperature=1.0):
+    """Symmetric soft-target cross entropy (:293-302).  The targets are NOT detached in the reference: gradients
+    flow through them as well."""
+    logits = CB_emb @ MT_emb.T / temperature
+    targets = torch.softmax((MT_emb @ MT_emb.T + CB_emb @ CB_emb.T) / 2 * temperature, dim=-1)
+    texts = (-targets * torch.log_softmax(logits, dim=-1)).sum(1)
+    images = (-targets.T * torch.log_softmax(logits.T, dim=-1)).sum(1)
+    loss = (images + texts) / 2.0
+    return loss.mean(), loss
+
+
+def clip_forward(sd, head_sd, cfg, batch, CB_features, temperature=1.0):
+    """CLIPModel.forward (:243-302) given the ChemBERTa features: MT features = the fingerprint output of the
+    encoder half (fourth return value of MultimodalTransformer.forward without a target, :278-285)."""
+    memory, _, mask, fingerprint = forward(sd, cfg, batch, None)
+    CB_emb = projection_head(CB_features, head_sd, "CB_projection.")
+    MT_emb = projection_head(fingerprint, head_sd, "MT_projection.")
+    return clip_loss(CB_emb, MT_emb, temperature)
+
+
+# ----------------------------------------------------------------------------
 # beam search (validate_generate_MMT_v15_4.py:995-1094)
 # ----------------------------------------------------------------------------
 

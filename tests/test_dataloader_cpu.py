@@ -121,3 +121,24 @@ def test_iter_batches_shards_like_distributed_sampler():
     tr = D.MultimodalData(cfg("1H", 0.0), stoi, stoi_MF, "train")
     te = D.MultimodalData(cfg("1H", 0.0), stoi, stoi_MF, "test")
     assert len(tr) == int(0.9 * n) and len(tr) + len(te) == n
+
+
+def test_weight_sorted_batches_match_reference_sampler():
+    """Fixture: the reference's WeightSortedBatchSampler (clip_functions_v15_4.py:117-152) run with random.seed(5)."""
+    import random
+    import numpy as np
+    from multimodalspectraltransformer_amd.dataloaders import weight_sorted_batches
+    from tests.util import load_golden
+    g = load_golden("clip_c2_L1")
+    mw = g["sampler_mw"].tolist()
+    n = 0
+    for key in g.files:
+        if not key.startswith("sampler/"):
+            continue
+        bs, ws, dl = key[len("sampler/"):].split("_")
+        random.seed(5)
+        got = list(weight_sorted_batches(mw, int(bs), bool(int(dl)), None if ws == "None" else int(ws), rng=random))
+        want = [[i for i in row if i >= 0] for row in g[key].tolist()]
+        assert got == want, key
+        n += 1
+    assert n == 3

@@ -99,6 +99,32 @@ def test_greedy_tokens_identical(name, mode):
     assert O.tensor_to_smiles(toks, itos) == [str(s) for s in g["smiles"]]
 
 
+def test_clip_head_matches_reference():
+    """Oracle CLIP head + loss against the reference's CLIPModel.forward (models_CLIP_v15_4.py:243-302) with the
+    ChemBERTa features given: loss, per-sample losses, gradients."""
+    g = load_golden("clip_c2_L1")
+    mode, nl, B = "1H_HSQC_COSY_IR_MF_MW", int(g["nl"]), int(g["B"])
+    cfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    sd = {k: v.requires_grad_(True) for k, v in O.make_state_dict(cfg, int(g["wseed"])).items()}
+    head = {k: v.requires_grad_(True) for k, v in O.make_clip_head_state_dict(int(g["hseed"])).items()}
+    batch = O.synthetic_batch(B, int(g["seed"]), mode)
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"]) + 1000))
+    cb = torch.from_numpy(rng.standard_normal((B, O.CLIP_DIMS["CB_embedding"])).astype(np.float32))
+    loss, losses = O.clip_forward(sd, head, cfg, batch, cb, 1.0)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    np.testing.assert_allclose(losses.detach().numpy(), g["losses"], rtol=1e-3, atol=1e-4)
+    checked = 0
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        p = head[name] if name in head else sd[name[len("MT_model."):]]
+        digest_close(digest(p.grad), g[k], 5e-3, 1e-6)
+        checked += 1
+    assert checked >= 15
+
+
 def test_beam_search_identical():
     """Oracle beam search against the reference's beams (validate_generate_MMT_v15_4.py:1056)."""
     g = load_golden("beam_c2_L2")
