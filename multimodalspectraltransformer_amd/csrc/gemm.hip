@@ -236,10 +236,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
   }
 }
 
-int gemm_waves(bool wgrad) {
+// Waves per workgroup by epilogue.  Eight everywhere except the LayerNorm-backward epilogue: its 160 registers
+// allow one 8-wave workgroup per CU only, and a 291-tile launch then needs two rounds (45 us against 30 us with
+// two resident 4-wave workgroups).  Environment: MMST_GEMM_WAVES, MMST_GEMM_WAVES_WGRAD, MMST_GEMM_WAVES_LNBWD.
+int gemm_waves(int epi) {
   static const int v = [] { const char* e = getenv("MMST_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
   static const int w = [] { const char* e = getenv("MMST_GEMM_WAVES_WGRAD"); return (e && atoi(e) == 4) ? 4 : 8; }();
-  return wgrad ? w : v;
+  static const int l = [] { const char* e = getenv("MMST_GEMM_WAVES_LNBWD"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  return epi == EPI_ATOMIC ? w : epi == EPI_LNBWD ? l : v;
 }
 
 // Experiment switch: MMST_WGRAD_LDS_PAD=<bytes> pads EVERY split-K launch (see GemmBatch::lds_pad).
@@ -259,12 +263,12 @@ int dispatch_nw(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
 }
 template <int EPI>
 int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
-  return gemm_waves(EPI == EPI_ATOMIC) == 4 ? dispatch_nw<EPI, 4>(b, pt, qt, grid, s) : dispatch_nw<EPI, 8>(b, pt, qt, grid, s);
+  return gemm_waves(EPI) == 4 ? dispatch_nw<EPI, 4>(b, pt, qt, grid, s) : dispatch_nw<EPI, 8>(b, pt, qt, grid, s);
 }
 
 }  // namespace
 
-int gemm_waves_for(int epi) { return gemm_waves(epi == EPI_ATOMIC); }
+int gemm_waves_for(int epi) { return gemm_waves(epi); }
 
 GemmTap g_gemm_tap = {-1, 0, 0, 0, 0, nullptr, nullptr, 0.0, 0.0};
 
