@@ -357,6 +357,7 @@ __global__ void attn_q_kernel(const AttnBatch batch) {
     const TailCtx tc = {scale, scale2, dscale, thr, dropping};
     for (int t = 0; t < tail_o; ++t) q_owner_tail<BWD>(pr, tc, b, hh, Tq_main + t, lane);
   }
+  if (TAILS && Tq_main == 0) return;   // uniform over the workgroup: nothing left for the tiled path
   const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)));
 
   bf16x8 qf[C::KS], dof[C::KS];
@@ -558,6 +559,7 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
     const TailCtx tc = {scale, scale2, dscale, thr, dropping};
     for (int t = 0; t < tail_o; ++t) kv_owner_tail(pr, tc, b, hh, Sk_main + t, lane);
   }
+  if (TAILS && Sk_main == 0) return;
   const uint32_t pair_term = (uint32_t)(key >> 1) * ATTN_PAIR_MUL;
   const uint32_t pair_shift = (key & 1) ? 16u : 0u;
 
@@ -662,8 +664,10 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
 // rows of a side that are handled outside the MFMA tiling (see "Tail rows" above)
 int tail_of(const AttnBatch& b, int rows) {
   static const int enabled = [] { const char* e = getenv("MMST_ATTN_TAILS"); return e ? atoi(e) : 1; }();
+  if (!enabled || b.hd != 8 || b.causal) return 0;
+  if (rows <= 2) return rows;   // a side of one or two rows (a cached decode step): no MFMA tile at all on it
   const int r = rows & 31;
-  return (enabled && b.hd == 8 && !b.causal && rows >= 64 && r >= 1 && r <= 2) ? r : 0;
+  return (rows >= 64 && r >= 1 && r <= 2) ? r : 0;
 }
 
 // workgroups per (batch, head group): one per TPB owner tiles
@@ -675,6 +679,7 @@ void plan(AttnBatch& b, bool owner_is_key, int (&bpb)[ATTN_MAX_GROUPS]) {
     int rows = (owner_is_key ? b.p[i].Sk : b.p[i].Tq) - b.p[i].tail_o;
     int tiles = (rows + 31) / 32;
     bpb[i] = (tiles + tpb - 1) / tpb;
+    if (bpb[i] == 0) bpb[i] = 1;   // every owner row is a tail row: one workgroup per (batch, head group) serves them
   }
 }
 

@@ -100,7 +100,7 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
 
     With MMST_DECODE_GRAPH=1 greedy decoding replays one hipGraph per target position (captured on first use, kept
     with the plan): a token is ~50 small launches whose arguments depend only on the position.  Measured on an
-    MI355X at 64 molecules x 128 tokens the replay is no faster than issuing the launches directly (67 ms either
+    MI355X at 64 molecules x 128 tokens the replay is no faster than issuing the launches directly (52 ms either
     way: the token step is bound by the latency of its chain of small kernels, not by the host), so it is off by
     default.  The all-<PAD> stop test needs the tokens on the host, so it runs every 8th position; positions
     decoded past the stop are cut off, which gives exactly the reference's output."""

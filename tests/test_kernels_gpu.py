@@ -392,7 +392,7 @@ def test_attn_causal(T):
     run_attn(2, 16, T, T, 8, causal=True, use_bias=False)
 
 
-@pytest.mark.parametrize("T,S", [(63, 582), (1, 453), (128, 902), (65, 130), (129, 64), (64, 98), (1, 66)])
+@pytest.mark.parametrize("T,S", [(63, 582), (1, 453), (128, 902), (65, 130), (129, 64), (64, 98), (1, 66), (2, 130), (1, 128), (1, 7), (2, 9)])
 def test_attn_cross(T, S):
     run_attn(2, 16, T, S, 8, causal=False, use_bias=True, self_attn=False)
 
