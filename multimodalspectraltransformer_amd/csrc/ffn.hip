@@ -43,9 +43,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base + 16 * lane)
 __device__ __forceinline__ void glds16(const bf16* src, unsigned char* dst) {
-#ifndef FFN_NO_DMA
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-#endif
 }
 
 enum ImgKind { IMG_W1_FWD, IMG_W2_FWD, IMG_H_BWD };

@@ -56,9 +56,6 @@ __device__ __forceinline__ void r2s(unsigned char* img, const uint4 (&r)[NL], in
 
 template <bool QSW>
 __device__ __forceinline__ bf16x8 frag_n(const unsigned char* img, int row, int ks, int lane) {
-#ifdef FFN_NO_LDS
-  { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (bf16)(float)(row + ks + e); return z; }
-#endif
   int chunk = ks * 4 + (lane >> 4);
   int key = QSW ? fsw(row) : (row & 7);
   return *reinterpret_cast<const bf16x8*>(img + row * 128 + ((chunk ^ key) << 4));

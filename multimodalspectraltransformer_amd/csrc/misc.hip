@@ -100,11 +100,12 @@ struct EmbedBwdArgs {
   const bf16* dx[MMST_MAX_GROUPS];
 };
 
-// one block = one (group, batch element); thread = column.  Point-embedding and MW gradients are
-// reduced over the sequence in registers (one atomic per column per block); embedding-table rows
-// are scatter-added.
-__global__ void embed_bwd_kernel(const EmbedBwdArgs A) {
-  const int gi = blockIdx.y, b = blockIdx.x, c = threadIdx.x;
+// one block = one (group, batch element); 8 row groups x 128 columns: the sequence positions are strided over the
+// row groups (every load of a thread is independent), point-embedding sums are combined through LDS (one atomic per
+// column per block), embedding-table rows are scatter-added.
+__global__ __launch_bounds__(1024) void embed_bwd_kernel(const EmbedBwdArgs A) {
+  __shared__ float red[3][8][D];
+  const int gi = blockIdx.y, b = blockIdx.x, c = threadIdx.x & (D - 1), grp = threadIdx.x >> 7;
   const mmst_embed_group& G = A.e.g[gi];
   const mmst_embed_shared& S = A.e.s;
   const bf16* dx = A.dx[gi] + (size_t)b * G.S * D;
@@ -112,34 +113,48 @@ __global__ void embed_bwd_kernel(const EmbedBwdArgs A) {
   int s = 0;
   if (G.in_dim > 0) {
     float dw0 = 0.f, dw1 = 0.f, db = 0.f;
-    for (; s < 64; ++s) {
-      float gsc = (float)x[s * D + c] > 0.f ? (float)dx[s * D + c] : 0.f;
-      const float* xin = G.src + ((size_t)b * 64 + s) * G.in_dim;
+    for (int r = grp; r < 64; r += 8) {
+      float gsc = (float)x[r * D + c] > 0.f ? (float)dx[r * D + c] : 0.f;
+      const float* xin = G.src + ((size_t)b * 64 + r) * G.in_dim;
       dw0 += gsc * xin[0];
       if (G.in_dim == 2) dw1 += gsc * xin[1];
       db += gsc;
     }
-    atomicAdd(G.dw + (size_t)c * G.in_dim, dw0);
-    if (G.in_dim == 2) atomicAdd(G.dw + (size_t)c * G.in_dim + 1, dw1);
-    atomicAdd(G.db + c, db);
+    red[0][grp][c] = dw0;
+    red[1][grp][c] = dw1;
+    red[2][grp][c] = db;
+    __syncthreads();
+    if (grp == 0) {
+      dw0 = dw1 = db = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dw0 += red[0][i][c]; dw1 += red[1][i][c]; db += red[2][i][c]; }
+      atomicAdd(G.dw + (size_t)c * G.in_dim, dw0);
+      if (G.in_dim == 2) atomicAdd(G.dw + (size_t)c * G.in_dim + 1, dw1);
+      atomicAdd(G.db + c, db);
+    }
+    s = 64;
   } else {
     // IR row: its weight gradient is a GEMM; emit the gradient in front of the ReLU for it
-    if (G.ir_dpre) ((bf16*)G.ir_dpre)[(size_t)b * D + c] = (float)x[c] > 0.f ? dx[c] : (bf16)0.f;
+    if (G.ir_dpre && grp == 0) ((bf16*)G.ir_dpre)[(size_t)b * D + c] = (float)x[c] > 0.f ? dx[c] : (bf16)0.f;
     s = G.n_spec;
   }
   if (S.has_mf) {
-    for (int t = 0; t < 64; ++t, ++s) {
+    for (int t = grp; t < 64; t += 8) {
       const int64_t tok = S.mf_tok[(size_t)b * 64 + t];
-      if (tok != 0 && (float)x[s * D + c] > 0.f) atomicAdd(S.d_mf_table + (size_t)tok * D + c, (float)dx[s * D + c]);
+      const int r = s + t;
+      if (tok != 0 && (float)x[r * D + c] > 0.f) atomicAdd(S.d_mf_table + (size_t)tok * D + c, (float)dx[r * D + c]);
     }
+    s += 64;
   }
   if (S.has_ms) {
-    for (int t = 0; t < 64; ++t, ++s) {
+    for (int t = grp; t < 64; t += 8) {
       const int64_t tok = S.ms_tok[(size_t)b * 64 + t];
-      if (tok != 0 && (float)x[s * D + c] > 0.f) atomicAdd(S.d_ms_table + (size_t)tok * D + c, (float)dx[s * D + c]);
+      const int r = s + t;
+      if (tok != 0 && (float)x[r * D + c] > 0.f) atomicAdd(S.d_ms_table + (size_t)tok * D + c, (float)dx[r * D + c]);
     }
+    s += 64;
   }
-  if (S.has_mw) {
+  if (S.has_mw && grp == 0) {
     float gsc = (float)x[s * D + c] > 0.f ? (float)dx[s * D + c] : 0.f;
     atomicAdd(S.d_mw_w + c, gsc * S.mw[b]);
     atomicAdd(S.d_mw_b + c, gsc);
@@ -383,7 +398,7 @@ int mmst_embed_bwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s,
     if (!dxseq[i]) return MMST_ERR_ARG;
     A.dx[i] = (const bf16*)dxseq[i];
   }
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(s->B, n), dim3(D), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(s->B, n), dim3(8 * D), 0, (hipStream_t)stream, A);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
