@@ -90,8 +90,7 @@ int mmst_tap_read(float* total_ms, int* count, double* flops, double* bytes, cha
   if (count) *count = t.count;
   if (flops) *flops = t.flops;
   if (bytes) *bytes = t.bytes;
-  if (name && cap > 0) snprintf(name, cap, "gemm_kernel<%d, %s, %s, %d>", t.epi, t.pt ? "true" : "false", t.qt ? "true" : "false",
-                                 gemm_waves_for(t.epi));
+  if (name && cap > 0) gemm_kernel_name(t.epi, t.pt != 0, t.qt != 0, name, cap);
   return MMST_OK;
 }
 

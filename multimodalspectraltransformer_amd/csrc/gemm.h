@@ -47,6 +47,7 @@ struct GemmBatch {
 };
 
 int gemm_waves_for(int epi);   // waves per workgroup of the kernel variant that serves this epilogue
+void gemm_kernel_name(int epi, bool pt, bool qt, char* out, int cap);
 
 // Diagnostic tap (bench.py): HIP events around every launch of ONE kernel variant, on the launch stream.
 struct GemmTap {
