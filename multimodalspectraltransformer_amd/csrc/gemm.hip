@@ -250,9 +250,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NS>
-__global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const GemmBatch batch) {
-  constexpr int NW = 8, MT = 2, NT = 4, IMG = BP * BK * 2, STAGE = 2 * IMG, AHEAD = NS - 1;
+template <int NS, int KB>   // NS pipeline stages of KB (64 or 32) contraction rows
+__global__ __launch_bounds__(512, NS * KB <= 128 ? 2 : 1) void wgrad_dma_kernel(const GemmBatch batch) {
+  constexpr int NW = 8, MT = 2, NT = 4, IMG = BP * KB * 2, STAGE = 2 * IMG, AHEAD = NS - 1, NJ = KB / 32;
   constexpr int SMEM = NS * STAGE > NW * 32 * 65 * 4 ? NS * STAGE : NW * 32 * 65 * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,8 +273,10 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const G
   const int ks_id = local / pr.ptiles;
   const int p0 = ptile * BP, q0 = qt * BQ;
   const int pw0 = (wave >> 1) * 32, qw0 = (wave & 1) * 64;
-  const int K = pr.K, nk = (K + BK - 1) / BK;
-  const int kbeg = (int)(((long)nk * ks_id) / pr.ksplit), kend = (int)(((long)nk * (ks_id + 1)) / pr.ksplit);
+  const int K = pr.K, nk64 = (K + BK - 1) / BK;   // the K split is planned in 64-row units
+  const int kbeg = (int)(((long)nk64 * ks_id) / pr.ksplit) * (BK / KB);
+  int kend = (int)(((long)nk64 * (ks_id + 1)) / pr.ksplit) * (BK / KB);
+  if (kend * KB >= K + KB) kend = (K + KB - 1) / KB;   // no empty trailing step
   const int nsteps = kend - kbeg;
 
   f32x4 acc[MT][NT];
@@ -291,24 +293,24 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const G
   for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 
   // this lane's share of a step: DMA instruction j of the wave fills image rows (2 wave + j) * 4 .. + 3
-  int rrow[2], rcol[2];
+  int rrow[NJ], rcol[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    rrow[j] = (wave * 2 + j) * 4 + (lane >> 4);
+  for (int j = 0; j < NJ; ++j) {
+    rrow[j] = (wave * NJ + j) * 4 + (lane >> 4);
     const int c16 = lane & 15;
     rcol[j] = (((c16 >> 1) ^ fsw(rrow[j])) << 4) + ((c16 & 1) << 3);   // logical column (elements) of this LDS slot
   }
   auto issue = [&](int step) {
-    const int k0 = (kbeg + step) * BK;
+    const int k0 = (kbeg + step) * KB;
     unsigned char* st = smem + (step % NS) * STAGE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       int row = k0 + rrow[j];
       row = row < K ? row : K - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(pr.P + (size_t)row * pr.ldp + p0 + rcol[j]),
-                                       (lptr_t)(st + (wave * 2 + j) * 1024), 16, 0, 0);
+                                       (lptr_t)(st + (wave * NJ + j) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(pr.Q + (size_t)row * pr.ldq + q0 + rcol[j]),
-                                       (lptr_t)(st + IMG + (wave * 2 + j) * 1024), 16, 0, 0);
+                                       (lptr_t)(st + IMG + (wave * NJ + j) * 1024), 16, 0, 0);
     }
   };
 #pragma unroll
@@ -316,22 +318,27 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const G
     if (s0 < nsteps) issue(s0);
 
   for (int step = 0; step < nsteps; ++step) {
-    // own DMA of this step has landed once only the younger steps' (4 instructions each) are outstanding
+    // own DMA of this step has landed once only the younger steps' (2 NJ instructions each) are outstanding
     if (step + AHEAD - 1 < nsteps) {
-      if (AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (AHEAD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      constexpr int YOUNGER = (AHEAD - 1) * 2 * NJ;
+      if (YOUNGER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (YOUNGER == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (YOUNGER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (YOUNGER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (YOUNGER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      static_assert(YOUNGER == 0 || YOUNGER == 2 || YOUNGER == 4 || YOUNGER == 6 || YOUNGER == 8 || YOUNGER == 12, "wait count");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     unsigned char* st = smem + (step % NS) * STAGE;
-    if ((kbeg + step + 1) * BK > K) {   // ragged last step: rows >= K must not contribute (products, column sums)
-      const int k0 = (kbeg + step) * BK;
+    if ((kbeg + step + 1) * KB > K) {   // ragged last step: rows >= K must not contribute (products, column sums)
+      const int k0 = (kbeg + step) * KB;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
         if (k0 + rrow[j] >= K) {
-          *reinterpret_cast<uint4*>(st + (wave * 2 + j) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
-          *reinterpret_cast<uint4*>(st + IMG + (wave * 2 + j) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(st + (wave * NJ + j) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(st + IMG + (wave * NJ + j) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
         }
     }
     __builtin_amdgcn_s_barrier();
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const G
     const unsigned char* Pimg = st;
     const unsigned char* Qimg = st + IMG;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KB / 32; ++ks) {
       s16x4 plo[MT], phi[MT], qlo[NT], qhi[NT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) frag_t_issue(plo[mt], phi[mt], Pimg, pw0 + mt * 16 + 4 * (lane & 3), ks, lane);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void wgrad_dma_kernel(const G
 // (64 KiB feed-forward backward, 50-70 KiB attention) off the CUs they occupy.
 int wgrad_dma_stages() {
   static const int v = [] { const char* e = getenv("MMST_WGRAD_DMA"); return e ? atoi(e) : 2; }();
-  return (v >= 2 && v <= 4) ? v : 0;
+  return (v >= 2 && v <= 4) || v == 34 || v == 36 ? v : 0;   // 34 / 36: 4 / 6 stages of 32 rows
 }
 bool wgrad_dma_ok(const GemmBatch& b) {
   for (int i = 0; i < b.n; ++i) {
@@ -440,9 +447,13 @@ template <int EPI>
 int dispatch(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
   if (EPI == EPI_ATOMIC && pt && qt && wgrad_dma_stages() && wgrad_dma_ok(b)) {
     const int dyn = b.lds_pad > wgrad_lds_pad() ? b.lds_pad : wgrad_lds_pad();
-    if (wgrad_dma_stages() == 2) hipLaunchKernelGGL((wgrad_dma_kernel<2>), dim3(grid), dim3(512), dyn, s, b);
-    else if (wgrad_dma_stages() == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3>), dim3(grid), dim3(512), dyn, s, b);
-    else hipLaunchKernelGGL((wgrad_dma_kernel<4>), dim3(grid), dim3(512), dyn, s, b);
+    switch (wgrad_dma_stages()) {
+      case 2: hipLaunchKernelGGL((wgrad_dma_kernel<2, 64>), dim3(grid), dim3(512), dyn, s, b); break;
+      case 3: hipLaunchKernelGGL((wgrad_dma_kernel<3, 64>), dim3(grid), dim3(512), dyn, s, b); break;
+      case 4: hipLaunchKernelGGL((wgrad_dma_kernel<4, 64>), dim3(grid), dim3(512), dyn, s, b); break;
+      case 34: hipLaunchKernelGGL((wgrad_dma_kernel<4, 32>), dim3(grid), dim3(512), dyn, s, b); break;
+      default: hipLaunchKernelGGL((wgrad_dma_kernel<6, 32>), dim3(grid), dim3(512), dyn, s, b); break;
+    }
     return MMST_OK;
   }
   return gemm_waves(EPI) == 4 ? dispatch_nw<EPI, 4>(b, pt, qt, grid, s) : dispatch_nw<EPI, 8>(b, pt, qt, grid, s);
@@ -455,7 +466,8 @@ int gemm_waves_for(int epi) { return gemm_waves(epi); }
 // name of the kernel that serves (epi, pt, qt) launches with full tiles, as a profiler prints it
 void gemm_kernel_name(int epi, bool pt, bool qt, char* out, int cap) {
   if (epi == EPI_ATOMIC && pt && qt && wgrad_dma_stages())
-    snprintf(out, cap, "wgrad_dma_kernel<%d>", wgrad_dma_stages());
+    snprintf(out, cap, "wgrad_dma_kernel<%d, %d>", wgrad_dma_stages() > 30 ? wgrad_dma_stages() - 30 : wgrad_dma_stages(),
+             wgrad_dma_stages() > 30 ? 32 : 64);
   else
     snprintf(out, cap, "gemm_kernel<%d, %s, %s, %d>", epi, pt ? "true" : "false", qt ? "true" : "false", gemm_waves(epi));
 }
