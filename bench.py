@@ -1,4 +1,4 @@
-"""Benchmark of the BASELINE.json metric: molecules/s of one TRAINING step (forward in train mode with
+"""Benchmark of the headline metric: molecules/s of one TRAINING step (forward in train mode with
 dropout 0.1, cross-entropy on every position, backward, gradient all-reduce, AdamW) of the 4-modality
 MultimodalTransformer (config_V8.json architecture, training_mode 1H_HSQC_COSY_IR_MF_MW, 64 molecules per
 GPU), on N MI355X of one node, one process per GPU.

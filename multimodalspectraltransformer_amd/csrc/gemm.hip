@@ -499,7 +499,10 @@ int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
     total += p.ptiles * p.qtiles * p.ksplit;
   }
   GemmTap& tap = g_gemm_tap;
-  const bool timed = tap.epi == epi && tap.pt == (int)pt && tap.qt == (int)qt && tap.count < tap.capacity;
+  // the tap times ONE kernel: with the LDS-DMA weight-gradient kernel on, only the launches that take it
+  const bool dma = epi == EPI_ATOMIC && pt && qt && wgrad_dma_stages() != 0;
+  const bool timed = tap.epi == epi && tap.pt == (int)pt && tap.qt == (int)qt && tap.count < tap.capacity &&
+                     (!dma || wgrad_dma_ok(b));
   if (timed) {
     for (int i = 0; i < b.n; ++i) {
       const GemmProb& p = b.p[i];
