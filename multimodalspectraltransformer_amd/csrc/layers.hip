@@ -4,6 +4,7 @@
 #include "attn.h"
 #include "ffn.h"
 #include "gemm.h"
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -185,15 +186,18 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
   return MMST_OK;
 }
 
-// ---- encoder layer backward, critical path: gradients of activations only ----
-int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                                const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
-  if (n < 1 || n > MMST_MAX_GROUPS || !p || !g || !a || !w || (nhead != 16 && nhead != 4)) return MMST_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream_;
-  const int hd = D / nhead;
-  GemmBatch gb;
-  gb.n = n;
-  // feed-forward block backward fused with norm1 backward: dz1 = LNbwd(((dzd2 W2) * mask(h)) W1 + dz2)
+}  // extern "C"
+
+namespace {
+
+inline bool enc_args_ok(int n, const void* p, const void* g, const void* a, const void* w, int nhead) {
+  return n >= 1 && n <= MMST_MAX_GROUPS && p && g && a && w && (nhead == 16 || nhead == 4);
+}
+
+// first part of the critical path: feed-forward block backward fused with norm1 backward,
+// dz1 = LNbwd(((dzd2 W2) * mask(h)) W1 + dz2).  Leaves dh, dz1 and dzd1 in w.
+int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
+                float drop_p, uint32_t seed, hipStream_t st) {
   FfnBatch fb;
   fb.n = n;
   int tiles = 0;
@@ -210,7 +214,15 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
     q.drop_p = drop_p; q.seed = seed + 8 * i + 1;
     fb.p[i] = f;
   }
-  RUN(launch_ffn_bwd(fb, st));
+  return launch_ffn_bwd(fb, st);
+}
+
+// second part of the critical path: out_proj, attention and in_proj backward.  Leaves dqkv in w.
+int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const mmst_enc_bwd* w, int nhead, float drop_p,
+                 uint32_t seed, hipStream_t st) {
+  const int hd = D / nhead;
+  GemmBatch gb;
+  gb.n = n;
   // da = dzd1 Wo
   for (int i = 0; i < n; ++i) {
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
@@ -248,21 +260,19 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
     }
     gb.p[i] = q;
   }
-  RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
-  return MMST_OK;
+  return launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st);
 }
 
-// ---- encoder layer backward, off the critical path: every parameter gradient of the layer as ONE grouped
-// split-K launch (all groups x {linear2, linear1, out_proj, in_proj}); reads what the data phase left in w ----
-int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                                   const mmst_enc_bwd* w, float drop_p, void* stream_) {
-  if (n < 1 || n > MMST_MAX_GROUPS || !p || !g || !a || !w) return MMST_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream_;
+// Parameter gradients of a layer as grouped split-K launches.  WG_EARLY: linear2, linear1 and out_proj, whose
+// inputs exist once enc_bwd_ffn has run; WG_LATE: in_proj, which needs dqkv from enc_bwd_attn.
+enum { WG_EARLY = 1, WG_LATE = 2 };
+int enc_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                    const mmst_enc_bwd* w, float drop_p, int which, hipStream_t st) {
   GemmProb probs[4 * MMST_MAX_GROUPS];
   int np = 0, tiles = 0;
   for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
   const bool recompute = ffn_wgrad_recompute() && tiles >= ffn_fuse_min_tiles();   // as in mmst_encoder_layer_bwd_data
-  if (recompute) {
+  if (recompute && (which & WG_EARLY)) {
     FfnWgradBatch wb;
     wb.n = n;
     for (int i = 0; i < n; ++i) {
@@ -276,14 +286,76 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_e
   for (int i = 0; i < n; ++i) {
     const int M = a[i].B * a[i].S;
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
-    if (!recompute) {
-      probs[np++] = wgrad(w[i].dzd2, M, D, a[i].h, FF, g[i].w_2, g[i].b_2);
-      probs[np++] = wgrad(w[i].dh, M, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+    if (which & WG_EARLY) {
+      if (!recompute) {
+        probs[np++] = wgrad(w[i].dzd2, M, D, a[i].h, FF, g[i].w_2, g[i].b_2);
+        probs[np++] = wgrad(w[i].dh, M, FF, a[i].x1, D, g[i].w_1, g[i].b_1);
+      }
+      probs[np++] = wgrad(dzd1, M, D, a[i].attn, D, g[i].w_o, g[i].b_o);
     }
-    probs[np++] = wgrad(dzd1, M, D, a[i].attn, D, g[i].w_o, g[i].b_o);
-    probs[np++] = wgrad(w[i].dqkv, M, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
+    if (which & WG_LATE) probs[np++] = wgrad(w[i].dqkv, M, 3 * D, a[i].x, D, g[i].w_qkv, g[i].b_qkv);
   }
   return launch_wgrads(probs, np, st);
+}
+
+// `to` waits for everything enqueued on `from` so far.  Events come from a per-device ring created on first
+// use (a wait holds the state its event had when the wait was enqueued, so a slot can be recorded again later).
+int stream_fork(hipStream_t from, hipStream_t to) {
+  constexpr int MAX_DEV = 16, RING = 64;
+  static hipEvent_t ring[MAX_DEV][RING];
+  static bool made[MAX_DEV];
+  static int next[MAX_DEV];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return MMST_ERR_ARG;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!made[dev]) {
+    for (int i = 0; i < RING; ++i)
+      if (hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming) != hipSuccess) return MMST_ERR_LAUNCH;
+    made[dev] = true;
+  }
+  hipEvent_t ev = ring[dev][next[dev]];
+  next[dev] = (next[dev] + 1) % RING;
+  if (hipEventRecord(ev, from) != hipSuccess) return MMST_ERR_LAUNCH;
+  if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) return MMST_ERR_LAUNCH;
+  return MMST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- encoder layer backward, critical path: gradients of activations only ----
+int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  if (!enc_args_ok(n, p, g, a, w, nhead)) return MMST_ERR_ARG;
+  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, (hipStream_t)stream_));
+  return enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, (hipStream_t)stream_);
+}
+
+// ---- encoder layer backward, off the critical path: every parameter gradient of the layer as ONE grouped
+// split-K launch (all groups x {linear2, linear1, out_proj, in_proj}); reads what the data phase left in w ----
+int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                   const mmst_enc_bwd* w, float drop_p, void* stream_) {
+  if (!enc_args_ok(n, p, g, a, w, 16)) return MMST_ERR_ARG;
+  return enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY | WG_LATE, (hipStream_t)stream_);
+}
+
+// ---- both halves on two streams, interleaved: the feed-forward and out_proj weight gradients (nearly all of the
+// layer's weight-gradient work, HBM- and MFMA-heavy) start on wstream as soon as the feed-forward backward is
+// done and so run beside the attention backward (VALU-bound) of the same layer instead of beside the next
+// layer's feed-forward backward; the in_proj gradient follows when dqkv exists ----
+int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                                   const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_,
+                                   void* wstream_) {
+  if (!enc_args_ok(n, p, g, a, w, nhead) || stream_ == wstream_) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
+  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, st));
+  RUN(stream_fork(st, wst));
+  RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
+  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st));
+  RUN(stream_fork(st, wst));
+  return enc_bwd_weights(n, p, g, a, w, drop_p, WG_LATE, wst);
 }
 
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
