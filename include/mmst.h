@@ -142,6 +142,30 @@ typedef struct {
 } mmst_dec_step;
 int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, int nhead, void* stream);
 
+/* ---- one new target position through ALL decoder layers in one launch (inference) ----
+ * Same inputs, caches and arithmetic as n_layers calls of mmst_decoder_layer_step (one workgroup per sequence walks
+ * the layers; matrix-vector products instead of GEMM tiles), optionally with the steps around them that the decode
+ * loops of the reference run per token (validate_generate_MMT_v15_4.py:747-762, models_MMT_v15_4.py:1240-1257):
+ * the embedding of the input token (tok != NULL), the vocabulary projection (logits != NULL) and the greedy choice
+ * softmax(logits / temperature) -> argmax, probability (next_tok != NULL).  p = array of n_layers parameter sets. */
+#define MMST_MAX_DEC_LAYERS 8
+typedef struct {
+  const void* x;               /* [B][128] bf16 input rows of this position (ignored when tok != NULL) */
+  const int64_t* tok;          /* optional [B] token ids: input row = bf16(embed[tok] + pos_row) */
+  const float* embed;          /* fp32 [vocabulary][128] */
+  const float* pos_row;        /* fp32 [128]: positional-embedding row of `pos` */
+  void* y;                     /* optional [B][128] bf16: output row of the last layer */
+  void* qkv_cache[MMST_MAX_DEC_LAYERS];   /* per layer, as mmst_dec_step.qkv_cache */
+  const void* kvc[MMST_MAX_DEC_LAYERS];   /* per layer, as mmst_dec_step.kvc */
+  const float* mem_bias;       /* [B][L] additive key bias, or NULL */
+  const void* w_out; const float* b_out;  /* optional vocabulary projection, bf16 [n_out][128] / fp32 [n_out] */
+  float* logits; int ld_logits; int n_out; /* out: logits[b*ld_logits + 0..n_out) fp32, n_out <= 64 */
+  int64_t* next_tok; float* next_prob;    /* optional [B]: greedy choice among logits[0..V) and its probability */
+  float temperature; int V;
+  int B, pos, cap, L;
+} mmst_dec_stack_step;
+int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, const mmst_dec_stack_step* s, int nhead, void* stream);
+
 typedef struct {
   const void* dz3; const void* dzd3;
   void* dh; void* dz2; void* dzd2; void* da; void* dqc; void* dkvc; void* dz1; void* dzd1; void* dqkv; float* delta;

@@ -90,7 +90,8 @@ def lib():
         if _lib.mmst_sizeof_gemm_batch() != C.sizeof(GemmBatch) or \
                 _lib.mmst_sizeof_attn_batch() != C.sizeof(AttnBatch) or \
                 _lib.mmst_sizeof_ffn_batch() != C.sizeof(FfnBatch) or \
-                _lib.mmst_sizeof_ffn_wgrad_batch() != C.sizeof(FfnWgradBatch):
+                _lib.mmst_sizeof_ffn_wgrad_batch() != C.sizeof(FfnWgradBatch) or \
+                _lib.mmst_sizeof_dec_stack_step() != C.sizeof(DecStackStep):
             raise MMSTError("struct layout mismatch between _lib.py and libmmst.so")
     return _lib
 
@@ -156,6 +157,17 @@ class DecActs(C.Structure):
 class DecStep(C.Structure):
     _fields_ = _ptrs("x", "y", "qkv_cache", "kvc", "mem_bias", "attn", "x1", "qc", "x2", "h", "lse", "ffn_ws") + [
         ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int)]
+
+
+MAX_DEC_LAYERS = 8
+
+
+class DecStackStep(C.Structure):
+    _fields_ = _ptrs("x", "tok", "embed", "pos_row", "y") + [
+        ("qkv_cache", C.c_void_p * MAX_DEC_LAYERS), ("kvc", C.c_void_p * MAX_DEC_LAYERS)] + _ptrs(
+        "mem_bias", "w_out", "b_out", "logits") + [("ld_logits", C.c_int), ("n_out", C.c_int)] + _ptrs(
+        "next_tok", "next_prob") + [("temperature", C.c_float), ("V", C.c_int),
+                                    ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int)]
 
 
 class DecBwd(C.Structure):

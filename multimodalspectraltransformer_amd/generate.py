@@ -70,8 +70,32 @@ class _StepState:
             s.B, s.pos, s.cap, s.L = B, 0, cap, pl.Lmem
             self.steps.append(s)
         self.out = self.rows[ndl % 2]
+        # the same position through all layers in one launch (mmst_decoder_stack_step)
+        self.params = (type(pl.dec_p[0]) * ndl)(*pl.dec_p)
+        ar = model._engine.arena
+        ss = self.stack = L.DecStackStep()
+        for l in range(ndl):
+            ss.qkv_cache[l] = self.cache[l].data_ptr()
+            ss.kvc[l] = self.steps[l].kvc
+        ss.mem_bias = self.steps[0].mem_bias
+        ss.embed = ar.p32("embed_trg.weight")
+        ss.y = self.out.data_ptr()
+        ss.w_out, ss.b_out = ar.pb("fc_out.weight"), ar.p32("fc_out.bias")
+        ss.logits, ss.ld_logits, ss.n_out = self.logits.data_ptr(), VPAD, VPAD
+        ss.V = model.out_size
+        ss.B, ss.pos, ss.cap, ss.L = B, 0, cap, pl.Lmem
+        self.ndl = ndl
         self.ops = ops
         self.graphs = {}   # (position, temperature) -> captured token step
+
+    def stack_step(self, tok_ptr, pe_ptr, pos, next_tok=None, next_prob=None, temperature=1.0):
+        """One position through the whole stack: embedding of the tokens at tok_ptr, all layers, logits, and (if
+        next_tok is given) the greedy choice."""
+        ss = self.stack
+        ss.tok, ss.pos_row, ss.pos = tok_ptr, pe_ptr + 4 * D * pos, pos
+        ss.next_tok, ss.next_prob, ss.temperature = next_tok, next_prob, float(temperature)
+        L.check(L.lib().mmst_decoder_stack_step(self.ndl, self.params, C.byref(ss), 16, L.stream_ptr()),
+                "mmst_decoder_stack_step")
 
     def refresh_memory(self, model, pl):
         """Copies of the projected memory keys/values and of the key bias for each of a molecule's sequences."""
@@ -122,7 +146,13 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
     emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
     use_graph = (not sample) and os.environ.get("MMST_DECODE_GRAPH", "0") == "1"
 
+    fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
+
     def enqueue(pos, select):
+        if fused:
+            stt.stack_step(tok[pos].data_ptr(), pe, pos, tok[pos + 1].data_ptr() if select else None,
+                           prob[pos].data_ptr() if select else None, temperature)
+            return
         L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok[pos].data_ptr()), B, C.c_void_p(emb), C.c_void_p(pe + 4 * D * pos),
                                        C.c_void_p(stt.rows[0].data_ptr()), B, 1, C.c_float(0.0), C.c_uint32(0), st()),
                 "mmst_trg_embed_fwd")
@@ -260,6 +290,7 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
     stt.refresh_memory(model, pl)
     dev = stt.logits.device
     emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
+    fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
     tok = torch.zeros(B * W, dtype=torch.long, device=dev)
     beams = [[(1, [sos], [])] for _ in range(B)]
     for idx in range(gen_len):
@@ -281,14 +312,18 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
                     row.append((slot, beam))
             slots.append(row)
         tok.copy_(torch.tensor(toks, dtype=torch.long), non_blocking=False)
-        L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok.data_ptr()), B * W, C.c_void_p(emb), C.c_void_p(pe + 4 * D * idx),
-                                       C.c_void_p(stt.rows[0].data_ptr()), B * W, 1, C.c_float(0.0), C.c_uint32(0), st()),
-                "mmst_trg_embed_fwd")
-        for l, s in enumerate(stt.steps):
-            s.pos = idx
-            L.check(lib.mmst_decoder_layer_step(C.byref(pl.dec_p[l]), C.byref(s), 16, st()), "mmst_decoder_layer_step")
-        stt.ops.gemm([dict(P=stt.out, Q=ar.pb("fc_out.weight"), C=stt.logits, bias=ar.p32("fc_out.bias"),
-                           ldp=D, ldq=D, ldc=VPAD, Pn=B * W, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
+        if fused:
+            stt.stack_step(tok.data_ptr(), pe, idx)
+        else:
+            L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok.data_ptr()), B * W, C.c_void_p(emb),
+                                           C.c_void_p(pe + 4 * D * idx), C.c_void_p(stt.rows[0].data_ptr()), B * W, 1,
+                                           C.c_float(0.0), C.c_uint32(0), st()), "mmst_trg_embed_fwd")
+            for l, s in enumerate(stt.steps):
+                s.pos = idx
+                L.check(lib.mmst_decoder_layer_step(C.byref(pl.dec_p[l]), C.byref(s), 16, st()),
+                        "mmst_decoder_layer_step")
+            stt.ops.gemm([dict(P=stt.out, Q=ar.pb("fc_out.weight"), C=stt.logits, bias=ar.p32("fc_out.bias"),
+                               ldp=D, ldq=D, ldc=VPAD, Pn=B * W, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
         probs = torch.softmax(stt.logits[:, :model.out_size], dim=1)      # :1038, no temperature
         top_p, top_i = torch.topk(probs, W, dim=1)
         top_p, top_i = top_p.cpu().tolist(), top_i.cpu().tolist()
