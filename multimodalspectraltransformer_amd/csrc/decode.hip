@@ -42,6 +42,23 @@ struct Smem {
 
 __device__ __forceinline__ float rbf(float v) { return (float)(bf16)v; }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its global
+// loads (__syncthreads() also drains those, which would serialise the loads issued ahead for later stages).
+// Nothing written to global memory here is read back inside the kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Two multiply-adds per instruction on packed bf16 pairs (v_dot2c_f32_bf16), fp32 accumulation.  Every vector that
+// enters a projection here is already bf16-exact, so packing it loses nothing; converting weights to fp32 and
+// multiplying them one by one costs four instructions per pair and makes a one-row projection VALU-bound.
+__device__ __forceinline__ bf16x2 pack2(float a, float b) { return bf16x2{(bf16)a, (bf16)b}; }
+__device__ __forceinline__ float dot8p(const bf16x8& w, const bf16x2 (&v)[4], float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 0, 1), v[0], acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 2, 3), v[1], acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 4, 5), v[2], acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 6, 7), v[3], acc, false);
+  return acc;
+}
+
 // out[n] = bias[n] + sum_k W[n][k] v[k] for K = 128, n < rows <= N (N a multiple of NT/8 or smaller than it): eight lanes
 // per output row (16 contiguous weights each), NT/8 rows per pass of the workgroup, the loads of U passes in
 // flight before the first one is consumed (a dependent L2 round trip per pass would dominate otherwise).
@@ -52,9 +69,12 @@ __device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const floa
   constexpr int RP = NT / 8, PASSES = (N + RP - 1) / RP;
   static_assert(PASSES % U == 0, "U must divide the number of passes");
   const int sub = tid & 7, r0 = tid >> 3;
-  float vin[16];
+  bf16x2 va[4], vb[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) vin[j] = v[sub * 16 + j];
+  for (int j = 0; j < 4; ++j) {
+    va[j] = pack2(v[sub * 16 + 2 * j], v[sub * 16 + 2 * j + 1]);
+    vb[j] = pack2(v[sub * 16 + 8 + 2 * j], v[sub * 16 + 8 + 2 * j + 1]);
+  }
 #pragma unroll 1
   for (int p0 = 0; p0 < PASSES; p0 += U) {
     bf16x8 a[U], b[U];
@@ -67,11 +87,7 @@ __device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const floa
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = (p0 + u) * RP + r0;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)a[u][j] * vin[j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)b[u][j] * vin[8 + j];
+      float s = dot8p(a[u], va, 0.f) + dot8p(b[u], vb, 0.f);
       s += __shfl_xor(s, 1);
       s += __shfl_xor(s, 2);
       s += __shfl_xor(s, 4);
@@ -87,11 +103,11 @@ __device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const flo
   constexpr int ROWS = D / NWAVE;   // rows per wave
   static_assert(ROWS % U == 0, "U must divide the rows per wave");
   const int lane = tid & 63, wave = tid >> 6;
-  float vin[32];
+  bf16x2 vin[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vin[c * 8 + j] = v[c * 512 + lane * 8 + j];
+    for (int j = 0; j < 4; ++j) vin[c][j] = pack2(v[c * 512 + lane * 8 + 2 * j], v[c * 512 + lane * 8 + 2 * j + 1]);
 #pragma unroll 1
   for (int i0 = 0; i0 < ROWS; i0 += U) {
     bf16x8 a[U][4];
@@ -102,11 +118,8 @@ __device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const flo
         a[u][c] = *reinterpret_cast<const bf16x8*>(W + (size_t)(wave * ROWS + i0 + u) * FF + c * 512 + lane * 8);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)a[u][c][j] * vin[c * 8 + j];
+      float s = (dot8p(a[u][0], vin[0], 0.f) + dot8p(a[u][1], vin[1], 0.f)) +
+                (dot8p(a[u][2], vin[2], 0.f) + dot8p(a[u][3], vin[3], 0.f));
       s = wave_sum(s);
       const int n = wave * ROWS + i0 + u;
       if (lane == 0) emit(n, s + (bias ? bias[n] : 0.f));
@@ -120,15 +133,15 @@ __device__ __forceinline__ void layernorm_row(Smem& sm, float z, const float* ga
   const bool own = tid < D;
   float s = wave_sum(own ? z : 0.f);
   if (lane == 0) sm.red[0][wave] = s;
-  __syncthreads();
+  lds_barrier();
   const float mean = (sm.red[0][0] + sm.red[0][1]) * (1.0f / D);
   const float d = own ? z - mean : 0.f;
   float vs = wave_sum(d * d);
   if (lane == 0) sm.red[1][wave] = vs;
-  __syncthreads();
+  lds_barrier();
   const float rstd = rsqrtf((sm.red[1][0] + sm.red[1][1]) * (1.0f / D) + 1e-5f);
   if (own) out[tid] = rbf(d * rstd * gamma[tid] + beta[tid]);
-  __syncthreads();
+  lds_barrier();
 }
 
 // Attention of one query row (sm q[128], 16 heads x 8) over `nkeys` keys: K row of key j at kbase + j*ld, V at
@@ -140,9 +153,9 @@ __device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kba
   const int lane = tid & 63, wave = tid >> 6;
   const int hh = lane & 15, slot = wave * 4 + (lane >> 4);
   const float scale2 = rsqrtf((float)HD) * LOG2E;
-  float qv[HD];
+  bf16x2 qv[4];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) qv[d] = q[hh * HD + d];
+  for (int j = 0; j < 4; ++j) qv[j] = pack2(q[hh * HD + 2 * j], q[hh * HD + 2 * j + 1]);
   float m = NEG_BIG, l = 0.f, acc[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) acc[d] = 0.f;
@@ -150,37 +163,37 @@ __device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kba
 #pragma unroll 1
   for (int k0 = slot; k0 < nkeys; k0 += U * STEP) {
     bf16x8 kt[U], vt[U];
-    float bt[U];
+    float sc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int key = min(k0 + u * STEP, nkeys - 1);
       kt[u] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)key * ld + hh * HD);
       vt[u] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)key * ld + hh * HD);
-      bt[u] = kbias ? kbias[key] * LOG2E : 0.f;
+      sc[u] = kbias ? kbias[key] * LOG2E : 0.f;
     }
+    // scores of the batch, one rescale of the running sums per batch
+    float mb = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int key = k0 + u * STEP;
-      if (key >= nkeys) break;
-      float kf[HD], vf[HD];
       if (last_k && key == nkeys - 1) {   // the row this workgroup has just produced: not yet visible in memory
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { kf[d] = last_k[hh * HD + d]; vf[d] = last_v[hh * HD + d]; }
-      } else {
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { kf[d] = (float)kt[u][d]; vf[d] = (float)vt[u][d]; }
+        for (int d = 0; d < HD; ++d) { kt[u][d] = (bf16)last_k[hh * HD + d]; vt[u][d] = (bf16)last_v[hh * HD + d]; }
       }
-      float dot = 0.f;
+      sc[u] = key < nkeys ? dot8p(kt[u], qv, 0.f) * scale2 + sc[u] : NEG_BIG;
+      mb = fmaxf(mb, sc[u]);
+    }
+    const float alpha = __builtin_amdgcn_exp2f(m - mb);
+    m = mb;
+    l *= alpha;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) dot += qv[d] * kf[d];
-      const float sc = dot * scale2 + bt[u];
-      const float mn = fmaxf(m, sc);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      const float p = __builtin_amdgcn_exp2f(sc - mn);
-      l = l * alpha + p;
-      m = mn;
+    for (int d = 0; d < HD; ++d) acc[d] *= alpha;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] = acc[d] * alpha + p * vf[d];
+    for (int u = 0; u < U; ++u) {
+      const float p = (k0 + u * STEP) < nkeys ? __builtin_amdgcn_exp2f(sc[u] - mb) : 0.f;
+      l += p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[d] += p * (float)vt[u][d];
     }
   }
   // merge the 4 key slots of the wave (lanes with equal head), then the waves through LDS
@@ -202,7 +215,7 @@ __device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kba
 #pragma unroll
     for (int d = 0; d < HD; ++d) sm.part[wave][hh][2 + d] = acc[d];
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < D) {
     const int h2 = tid >> 3, d = tid & 7;
     float MM = NEG_BIG;
@@ -217,7 +230,7 @@ __device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kba
     }
     sm.attn[tid] = rbf(A * (L > 0.f ? 1.0f / L : 0.f));
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) {
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     }
     sm.x[tid] = v;
   }
-  __syncthreads();
+  lds_barrier();
   const float* mbias = s.mem_bias ? s.mem_bias + (size_t)b * s.L : nullptr;
   for (int l = 0; l < args.n_layers; ++l) {
     const mmst_dec_params& p = args.p[l];
@@ -248,31 +261,31 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
       sm.qkv[n] = (float)r;
       crow[n] = r;
     });
-    __syncthreads();
+    lds_barrier();
     // 2. self-attention over positions 0..pos (every cached key is visible)
     attend(sm, sm.qkv, cache + D, cache + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv + D, sm.qkv + 2 * D, tid);
     // 3. out_proj + residual + norm1
     float z = 0.f;
     gemv_k128<D, 1>((const bf16*)p.w_o, p.b_o, sm.attn, tid, [&](int n, float v) { sm.qc[n] = v + sm.x[n]; });
-    __syncthreads();
+    lds_barrier();
     z = tid < D ? sm.qc[tid] : 0.f;
     layernorm_row(sm, z, p.g1, p.be1, sm.x1, tid);
     // 4. cross-attention query
     gemv_k128<D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, sm.x1, tid, [&](int n, float v) { sm.qc[n] = rbf(v); });
-    __syncthreads();
+    lds_barrier();
     // 5. cross-attention over the projected memory
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)b * s.L * 2 * D;
     attend(sm, sm.qc, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, tid);
     // 6. out_proj + residual + norm2
     gemv_k128<D, 1>((const bf16*)p.w_co, p.b_co, sm.attn, tid, [&](int n, float v) { sm.qc[n] = v + sm.x1[n]; });
-    __syncthreads();
+    lds_barrier();
     z = tid < D ? sm.qc[tid] : 0.f;
     layernorm_row(sm, z, p.g2, p.be2, sm.x2, tid);
     // 7. feed-forward block + norm3
     gemv_k128<FF, 8>((const bf16*)p.w_1, p.b_1, sm.x2, tid, [&](int n, float v) { sm.h[n] = rbf(fmaxf(v, 0.f)); });
-    __syncthreads();
+    lds_barrier();
     gemv_k2048<4>((const bf16*)p.w_2, p.b_2, sm.h, tid, [&](int n, float v) { sm.qc[n] = v + sm.x2[n]; });
-    __syncthreads();
+    lds_barrier();
     z = tid < D ? sm.qc[tid] : 0.f;
     layernorm_row(sm, z, p.g3, p.be3, sm.x, tid);
   }
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     lg[n] = v;
   }, s.n_out);
   if (!s.next_tok) return;
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {   // softmax(logits / temperature), first index of the maximum
     const int lane = tid;
     const float x = lane < s.V ? sm.qc[lane] / s.temperature : -INFINITY;

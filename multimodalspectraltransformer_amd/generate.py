@@ -4,9 +4,10 @@ Counterparts of utils_MMT/validate_generate_MMT_v15_4.py (run_model :95, greedy_
 multinomial_sequence :841, beam_search :1056) and of _generate_sequences (models_MMT_v15_4.py:1222-1297).  The decode
 loop keeps the reference's outputs (stop when every next token is <PAD>) but not its cost: the reference
 re-runs the decoder on the whole prefix for every token; here each step computes only the new position
-(mmst_decoder_layer_step: self-attention keys/values cached per layer, cross-attention keys/values of the
-memory projected once) and selects the token on the device.  MMST_DECODE_CACHED=0 (or cached=False) selects
-the prefix re-run, kept as the cross-check of the cached path.
+(self-attention keys/values cached per layer, cross-attention keys/values of the memory projected once) and
+selects the token on the device, one launch per token (mmst_decoder_stack_step; MMST_DECODE_FUSED=0 runs the
+same step as one mmst_decoder_layer_step per layer).  MMST_DECODE_CACHED=0 (or cached=False) selects the prefix
+re-run, kept as the cross-check of the cached path.
 """
 import ctypes as C
 import os
