@@ -156,13 +156,15 @@ typedef struct {
   const float* pos_row;        /* fp32 [128]: positional-embedding row of `pos` */
   void* y;                     /* optional [B][128] bf16: output row of the last layer */
   void* qkv_cache[MMST_MAX_DEC_LAYERS];   /* per layer, as mmst_dec_step.qkv_cache */
-  const void* kvc[MMST_MAX_DEC_LAYERS];   /* per layer, as mmst_dec_step.kvc */
-  const float* mem_bias;       /* [B][L] additive key bias, or NULL */
+  const void* kvc[MMST_MAX_DEC_LAYERS];   /* per layer, as mmst_dec_step.kvc ([B / kv_group][L][256]) */
+  const float* mem_bias;       /* [B / kv_group][L] additive key bias, or NULL */
   const void* w_out; const float* b_out;  /* optional vocabulary projection, bf16 [n_out][128] / fp32 [n_out] */
   float* logits; int ld_logits; int n_out; /* out: logits[b*ld_logits + 0..n_out) fp32, n_out <= 64 */
   int64_t* next_tok; float* next_prob;    /* optional [B]: greedy choice among logits[0..V) and its probability */
   float temperature; int V;
   int B, pos, cap, L;
+  int kv_group;                /* >= 1: sequences b*kv_group .. (b+1)*kv_group-1 share row block b of kvc and mem_bias
+                                  (the beams of one molecule); 0 is read as 1 */
 } mmst_dec_stack_step;
 int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, const mmst_dec_stack_step* s, int nhead, void* stream);
 

@@ -167,7 +167,8 @@ class DecStackStep(C.Structure):
         ("qkv_cache", C.c_void_p * MAX_DEC_LAYERS), ("kvc", C.c_void_p * MAX_DEC_LAYERS)] + _ptrs(
         "mem_bias", "w_out", "b_out", "logits") + [("ld_logits", C.c_int), ("n_out", C.c_int)] + _ptrs(
         "next_tok", "next_prob") + [("temperature", C.c_float), ("V", C.c_int),
-                                    ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int)]
+                                    ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int),
+                                    ("kv_group", C.c_int)]
 
 
 class DecBwd(C.Structure):

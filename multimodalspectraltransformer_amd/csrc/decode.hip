@@ -250,7 +250,8 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     sm.x[tid] = v;
   }
   lds_barrier();
-  const float* mbias = s.mem_bias ? s.mem_bias + (size_t)b * s.L : nullptr;
+  const int bm = b / s.kv_group;   // row block of the encoder memory this sequence reads
+  const float* mbias = s.mem_bias ? s.mem_bias + (size_t)bm * s.L : nullptr;
   for (int l = 0; l < args.n_layers; ++l) {
     const mmst_dec_params& p = args.p[l];
     bf16* cache = (bf16*)s.qkv_cache[l] + (size_t)b * s.cap * 3 * D;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     gemv_k128<D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, sm.x1, tid, [&](int n, float v) { sm.qc[n] = rbf(v); });
     lds_barrier();
     // 5. cross-attention over the projected memory
-    const bf16* kv = (const bf16*)s.kvc[l] + (size_t)b * s.L * 2 * D;
+    const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
     attend(sm, sm.qc, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, tid);
     // 6. out_proj + residual + norm2
     gemv_k128<D, 1>((const bf16*)p.w_co, p.b_co, sm.attn, tid, [&](int n, float v) { sm.qc[n] = v + sm.x1[n]; });
@@ -321,7 +322,8 @@ extern "C" int mmst_sizeof_dec_stack_step() { return (int)sizeof(mmst_dec_stack_
 extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, const mmst_dec_stack_step* s, int nhead,
                                        void* stream) {
   if (!p || !s || nhead != NH || n_layers < 1 || n_layers > MMST_MAX_DEC_LAYERS) return MMST_ERR_ARG;
-  if (s->B < 1 || s->pos < 0 || s->pos >= s->cap || s->L < 1) return MMST_ERR_ARG;
+  if (s->B < 1 || s->pos < 0 || s->pos >= s->cap || s->L < 1 || s->kv_group < 0) return MMST_ERR_ARG;
+  if (s->kv_group > 1 && s->B % s->kv_group != 0) return MMST_ERR_ARG;
   if (!s->tok && !s->x) return MMST_ERR_ARG;
   if (s->tok && (!s->embed || !s->pos_row)) return MMST_ERR_ARG;
   if (!s->y && !s->logits) return MMST_ERR_ARG;
@@ -334,6 +336,7 @@ extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, c
     a.p[l] = p[l];
   }
   a.s = *s;
+  if (a.s.kv_group < 1) a.s.kv_group = 1;
   a.n_layers = n_layers;
   hipLaunchKernelGGL(decode_stack_kernel, dim3(s->B), dim3(NT), 0, (hipStream_t)stream, a);
   MMST_CHECK_LAUNCH();

@@ -47,7 +47,8 @@ class _StepState:
         dev, B, cap = pl.cv.buf[torch.bfloat16].device, pl.B * rep, pl.cap_T
         ndl = model.num_decoder_layers
         self.rep, self.B = rep, B
-        if rep > 1:
+        self.copies = rep > 1 and os.environ.get("MMST_DECODE_FUSED", "1") == "0"   # only the per-layer step needs them
+        if self.copies:
             self.kvc = [torch.empty(B, pl.Lmem, 2 * D, dtype=torch.bfloat16, device=dev) for _ in range(ndl)]
             self.mem_bias = torch.empty(B, pl.Lmem, dtype=torch.float32, device=dev)
         bf = dict(dtype=torch.bfloat16, device=dev)
@@ -63,8 +64,8 @@ class _StepState:
             s = L.DecStep()
             s.x, s.y = self.rows[l % 2].data_ptr(), self.rows[(l + 1) % 2].data_ptr()
             s.qkv_cache = self.cache[l].data_ptr()
-            s.kvc = _P(pl.dec_acts[l]["kvc"]) if rep == 1 else self.kvc[l].data_ptr()
-            s.mem_bias = _P(pl.kbias_glob) if rep == 1 else self.mem_bias.data_ptr()
+            s.kvc = self.kvc[l].data_ptr() if self.copies else _P(pl.dec_acts[l]["kvc"])
+            s.mem_bias = self.mem_bias.data_ptr() if self.copies else _P(pl.kbias_glob)
             for f in ("attn", "x1", "qc", "x2", "h", "lse"):
                 setattr(s, f, getattr(self, f).data_ptr())
             s.ffn_ws = self.ws.data_ptr()
@@ -77,8 +78,9 @@ class _StepState:
         ss = self.stack = L.DecStackStep()
         for l in range(ndl):
             ss.qkv_cache[l] = self.cache[l].data_ptr()
-            ss.kvc[l] = self.steps[l].kvc
-        ss.mem_bias = self.steps[0].mem_bias
+            ss.kvc[l] = _P(pl.dec_acts[l]["kvc"])     # the sequences of a molecule share its memory rows (kv_group)
+        ss.mem_bias = _P(pl.kbias_glob)
+        ss.kv_group = rep
         ss.embed = ar.p32("embed_trg.weight")
         ss.y = self.out.data_ptr()
         ss.w_out, ss.b_out = ar.pb("fc_out.weight"), ar.p32("fc_out.bias")
@@ -99,7 +101,10 @@ class _StepState:
                 "mmst_decoder_stack_step")
 
     def refresh_memory(self, model, pl):
-        """Copies of the projected memory keys/values and of the key bias for each of a molecule's sequences."""
+        """Copies of the projected memory keys/values and of the key bias for each of a molecule's sequences (for
+        the per-layer token step; the one-launch step reads the molecule's rows directly)."""
+        if not self.copies:
+            return
         for l in range(model.num_decoder_layers):
             src = pl.cv.view(pl.dec_acts[l]["kvc"], pl.B, pl.Lmem, 2 * D)
             self.kvc[l].view(pl.B, self.rep, pl.Lmem, 2 * D).copy_(src.unsqueeze(1).expand(-1, self.rep, -1, -1))
@@ -280,7 +285,8 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
     if gen_len > pl.cap_T:
         raise L.MMSTError(f"gen_len {gen_len} exceeds the plan's capacity of {pl.cap_T} target positions")
     lib, st = L.lib(), L.stream_ptr
-    key = "_beam_state_%d" % W
+    fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
+    key = "_beam_state_%d_%d" % (W, fused)
     stt = getattr(pl, key, None)
     if stt is None:
         stt = _StepState(model, pl, rep=W)
@@ -291,7 +297,6 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
     stt.refresh_memory(model, pl)
     dev = stt.logits.device
     emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
-    fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
     tok = torch.zeros(B * W, dtype=torch.long, device=dev)
     beams = [[(1, [sos], [])] for _ in range(B)]
     for idx in range(gen_len):
