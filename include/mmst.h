@@ -177,6 +177,8 @@ typedef struct {
   void* dx; void* dxd;
   const void* prev_z3; const float* prev_st3; const float* prev_g3; float* prev_dg3; float* prev_dbe3;
   uint32_t prev_seed;
+  float* delta2;    /* optional scratch like delta, for the cross-attention: required by _bwd_streams, where the
+                       memory's dK/dV pass runs beside the self-attention backward that overwrites delta */
 } mmst_dec_bwd;
 
 /* Replaces nn.TransformerDecoderLayer.forward as called from :963 (causal tgt_mask built in-kernel,
@@ -190,6 +192,12 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
                                 const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
 int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts* a, const mmst_dec_bwd* w,
                                    float drop_p, void* stream);
+/* _data and _weights on two streams in one call: `stream` carries only what the next layer waits for; the dK/dV of
+ * the encoder memory, their projection into w->dmem and all parameter gradients go to `wstream` (made to wait for
+ * `stream` where needed).  join_dmem != 0: `stream` finally waits for the dmem update.  Same results as _bwd. */
+int mmst_decoder_layer_bwd_streams(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                                   const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, int join_dmem,
+                                   void* stream, void* wstream);
 
 /* Standalone LayerNorm backward (top of a layer stack): dy -> dz / dzd, accumulates dgamma, dbeta.
  * dy row (b, s) is read at row b*dy_L + dy_off + s when dy_L > 0 (a slice of the concatenated memory). */

@@ -174,7 +174,7 @@ class DecStackStep(C.Structure):
 class DecBwd(C.Structure):
     _fields_ = _ptrs("dz3", "dzd3", "dh", "dz2", "dzd2", "da", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta",
                      "da2", "dmem") + [("dmem_accumulate", C.c_int)] + _ptrs(
-        "dx", "dxd", "prev_z3", "prev_st3", "prev_g3", "prev_dg3", "prev_dbe3") + [("prev_seed", C.c_uint32)]
+        "dx", "dxd", "prev_z3", "prev_st3", "prev_g3", "prev_dg3", "prev_dbe3") + [("prev_seed", C.c_uint32)] + _ptrs("delta2")
 
 
 class EmbedGroup(C.Structure):

@@ -36,4 +36,6 @@ struct AttnBatch {
 
 int launch_attn_fwd(AttnBatch& b, hipStream_t stream);
 // dq pass also writes delta; dkv pass reads it: call dq first.
-int launch_attn_bwd(AttnBatch& b, hipStream_t stream);
+int launch_attn_bwd(AttnBatch& b, hipStream_t stream);      // = _q followed by _kv
+int launch_attn_bwd_q(AttnBatch& b, hipStream_t stream);    // dQ, delta
+int launch_attn_bwd_kv(AttnBatch& b, hipStream_t stream);   // dK, dV (reads delta)

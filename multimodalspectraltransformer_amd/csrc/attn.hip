@@ -726,14 +726,34 @@ int launch_attn_fwd(AttnBatch& b, hipStream_t stream) {
   return launch_q<false>(b, stream);
 }
 
-int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {
+namespace {
+int check_bwd(AttnBatch& b) {
   int rc = check(b);
   if (rc) return rc;
   for (int i = 0; i < b.n; ++i) {
     const AttnProb& p = b.p[i];
     if ((p.lddo & 7) || (p.lddq & 3) || (p.lddk & 3) || (p.lddv & 3)) return MMST_ERR_ARG;
   }
-  rc = launch_q<true>(b, stream);
+  return MMST_OK;
+}
+}  // namespace
+
+// dQ and delta (the row sums dO . O the dK/dV pass reads)
+int launch_attn_bwd_q(AttnBatch& b, hipStream_t stream) {
+  int rc = check_bwd(b);
+  if (rc) return rc;
+  return launch_q<true>(b, stream);
+}
+
+int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {
+  int rc = launch_attn_bwd_q(b, stream);
+  if (rc) return rc;
+  return launch_attn_bwd_kv(b, stream);
+}
+
+// dK and dV; needs delta from launch_attn_bwd_q
+int launch_attn_bwd_kv(AttnBatch& b, hipStream_t stream) {
+  int rc = check_bwd(b);
   if (rc) return rc;
   int bpb[ATTN_MAX_GROUPS];
   plan(b, true, bpb);

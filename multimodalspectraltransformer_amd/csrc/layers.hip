@@ -298,9 +298,10 @@ int enc_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, co
   return launch_wgrads(probs, np, st);
 }
 
-// `to` waits for everything enqueued on `from` so far.  Events come from a per-device ring created on first
+// `to` (if not null) waits for everything enqueued on `from` so far; the recorded event is handed back on request.
+// Events come from a per-device ring created on first
 // use (a wait holds the state its event had when the wait was enqueued, so a slot can be recorded again later).
-int stream_fork(hipStream_t from, hipStream_t to) {
+int stream_fork(hipStream_t from, hipStream_t to, hipEvent_t* recorded = nullptr) {
   constexpr int MAX_DEV = 16, RING = 64;
   static hipEvent_t ring[MAX_DEV][RING];
   static bool made[MAX_DEV];
@@ -317,7 +318,8 @@ int stream_fork(hipStream_t from, hipStream_t to) {
   hipEvent_t ev = ring[dev][next[dev]];
   next[dev] = (next[dev] + 1) % RING;
   if (hipEventRecord(ev, from) != hipSuccess) return MMST_ERR_LAUNCH;
-  if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) return MMST_ERR_LAUNCH;
+  if (to && hipStreamWaitEvent(to, ev, 0) != hipSuccess) return MMST_ERR_LAUNCH;
+  if (recorded) *recorded = ev;
   return MMST_OK;
 }
 
@@ -514,11 +516,17 @@ int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, in
   return MMST_OK;
 }
 
-// ---- decoder layer backward, critical path ----
-int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
-                                const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+}  // extern "C"
+
+namespace {
+
+// Decoder layer backward, activation gradients.  wst == nullptr: everything on st.  Otherwise the part of the
+// cross-attention backward that only feeds the encoder (dK/dV of the memory and their projection into dmem) goes
+// to wst: the next decoder layer does not wait for it.  join: st waits for that dmem update at its end (the
+// caller is about to read dmem on st).
+int dec_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a, const mmst_dec_bwd* w,
+                 int nhead, float drop_p, uint32_t seed, hipStream_t st, hipStream_t wst, bool join) {
   if (!p || !g || !a || !w || nhead != 16) return MMST_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream_;
   const int hd = D / nhead, M = a->B * a->T, ML = a->B * a->L;
   const bool dr = drop_p > 0.f;
   GemmBatch gb;
@@ -549,17 +557,26 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
     bf16* dkv = (bf16*)w->dkvc;
     q.Q = (const bf16*)a->qc; q.ldq = D; q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
     q.kbias = a->mem_bias; q.O = (bf16*)a->attn2; q.ldo = D; q.lse = a->lse2;
-    q.dO = (const bf16*)w->da2; q.lddo = D; q.delta = w->delta;
+    q.dO = (const bf16*)w->da2; q.lddo = D;
+    q.delta = w->delta2 ? w->delta2 : w->delta;   // own row sums when the dK/dV pass may run beside the self-attention
     q.dQ = (bf16*)w->dqc; q.lddq = D; q.dK = dkv; q.dV = dkv + D; q.lddk = q.lddv = 2 * D;
     q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->L; q.seed = seed + 2;
   }
-  RUN(launch_attn_bwd(ab, st));
+  if (wst && !w->delta2) return MMST_ERR_ARG;
+  RUN(launch_attn_bwd_q(ab, st));
+  hipEvent_t dmem_done = nullptr;
   {
+    hipStream_t kst = wst ? wst : st;
+    if (wst) RUN(stream_fork(st, wst));
+    RUN(launch_attn_bwd_kv(ab, kst));
+    GemmBatch gk;
+    gk.n = 1;
     GemmProb q = dgrad(w->dkvc, ML, 2 * D, (const bf16*)p->w_cqkv + D * D, D, w->dmem);
     if (w->dmem_accumulate) { q.R = (const bf16*)w->dmem; q.ldr = D; }
-    gb.p[0] = q;
+    gk.p[0] = q;
+    RUN(launch_gemm(gk, EPI_BIAS, false, true, kst));
+    if (wst && join) RUN(stream_fork(wst, nullptr, &dmem_done));
   }
-  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
   {
     GemmProb q = dgrad(w->dqc, M, D, p->w_cqkv, D, w->dz1);
     q.R = (const bf16*)w->dz2; q.ldr = D; q.Z = (bf16*)a->z1; q.stats = a->st1; q.gamma = p->g1;
@@ -597,7 +614,18 @@ int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* 
     gb.p[0] = q;
     RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
   }
+  if (dmem_done && hipStreamWaitEvent(st, dmem_done, 0) != hipSuccess) return MMST_ERR_LAUNCH;
   return MMST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- decoder layer backward, critical path ----
+int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                                const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  return dec_bwd_data(p, g, a, w, nhead, drop_p, seed, (hipStream_t)stream_, nullptr, false);
 }
 
 // ---- decoder layer backward, parameter gradients: one grouped split-K launch ----
@@ -625,6 +653,19 @@ int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, co
                            const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
   RUN(mmst_decoder_layer_bwd_data(p, g, a, w, nhead, drop_p, seed, stream_));
   return mmst_decoder_layer_bwd_weights(g, a, w, drop_p, stream_);
+}
+
+// ---- both halves on two streams: the activation gradients the next layer waits for on `stream`; the memory's
+// dK/dV, their projection into dmem and every parameter gradient on `wstream`.  join_dmem != 0: `stream` also
+// waits for the dmem update (set it for the last layer processed, before dmem is read) ----
+int mmst_decoder_layer_bwd_streams(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
+                                   const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, int join_dmem,
+                                   void* stream_, void* wstream_) {
+  if (!wstream_ || stream_ == wstream_) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
+  RUN(dec_bwd_data(p, g, a, w, nhead, drop_p, seed, st, wst, join_dmem != 0));
+  RUN(stream_fork(st, wst));
+  return mmst_decoder_layer_bwd_weights(g, a, w, drop_p, wstream_);
 }
 
 }  // extern "C"

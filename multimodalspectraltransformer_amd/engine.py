@@ -305,7 +305,7 @@ class Plan:
         for _ in range(ndl):
             sc = bwd_scratch(M, 16, max(Tm, 1))
             sc.update(dz2=cv.take(M * D), dzd2=cv.take(M * D), dqc=cv.take(M * D), da2=cv.take(M * D),
-                      dkvc=cv.take(B * Lm * 2 * D))
+                      dkvc=cv.take(B * Lm * 2 * D), delta2=cv.take(B * 16 * max(Tm, 1), f32))
             self.dec_bwd.append(sc)
         self.dmem = cv.take(B * Lm * D)
         self.dmem_in = cv.take(B * Lm * D)
@@ -435,7 +435,7 @@ class Plan:
             w, sc = L.DecBwd(), self.dec_bwd[l]
             w.dz3, w.dzd3 = _P(sc["dz"]), _P(sc["dzd"])
             self.dec_dzd.append((w.dz3, w.dzd3))
-            for f in ("dh", "dz2", "dzd2", "da", "da2", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta"):
+            for f in ("dh", "dz2", "dzd2", "da", "da2", "dqc", "dkvc", "dz1", "dzd1", "dqkv", "delta", "delta2"):
                 setattr(w, f, _P(sc[f]))
             w.dmem = _P(self.dmem)
             w.dmem_accumulate = 0 if l == ndl - 1 else 1
@@ -481,6 +481,8 @@ class Engine:
         self.device = None
         self.step_seed = 0x1234567
         self.interleave_wgrads = _INTERLEAVE_WGRADS
+        # decoder backward: the memory's dK/dV pass and its projection into dmem run on the weight-gradient stream
+        self.decoder_kv_on_wstream = os.environ.get("MMST_DEC_KV_WSTREAM", "1") != "0"
 
     # ------------------------------------------------------------------
     def ensure(self, device):
@@ -687,6 +689,12 @@ class Engine:
                 w = pl.dec_w[l]
                 w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
                 w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
+                if self.decoder_kv_on_wstream:
+                    L.check(lib.mmst_decoder_layer_bwd_streams(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]),
+                                                               C.byref(pl.dec_a[l]), C.byref(w), 16, C.c_float(p_drop),
+                                                               C.c_uint32(self.layer_seed(64 + l)), 1 if l == 0 else 0,
+                                                               st, wst), "mmst_decoder_layer_bwd_streams")
+                    continue
                 L.check(lib.mmst_decoder_layer_bwd_data(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
                                                         C.byref(w), 16, C.c_float(p_drop),
                                                         C.c_uint32(self.layer_seed(64 + l)), st),
