@@ -101,6 +101,7 @@ class Arena:
             p.data = view
         self.named = named
         self.shadow_stale = True
+        self.transposed_ready = None   # event after the last refresh of PbT on another stream than the caller's
 
     def owns(self, model):
         for k in (self.order[0], self.order[-1]):
@@ -630,6 +631,11 @@ class Engine:
                 "mmst_ce_loss")
         return pl.cv.view(pl.loss, 1)
 
+    def _side_stream(self, main):
+        if getattr(self, "wstream", None) is None or self.wstream.device != main.device:
+            self.wstream = torch.cuda.Stream(device=main.device)
+        return self.wstream
+
     # ------------------------------------------------------------------
     def backward(self, pl, train, on_segment=None, skip_decoder=False):
         """Backward of decode() + encode() from pl.dlogits; accumulates into the flat gradient buffer.
@@ -648,11 +654,11 @@ class Engine:
         p_drop2 = float(m.config.drop_out) if train else 0.0
         M = B * T
         main = torch.cuda.current_stream()
-        if getattr(self, "wstream", None) is None or self.wstream.device != main.device:
-            self.wstream = torch.cuda.Stream(device=main.device)
-        ws = self.wstream
+        ws = self._side_stream(main)
         st, wst = C.c_void_p(main.cuda_stream), C.c_void_p(ws.cuda_stream)
         ws.wait_stream(main)   # gradients were zeroed / forward finished on the main stream
+        if ar.transposed_ready is not None:   # FusedAdamW refreshes the transposed weights on the second stream
+            main.wait_event(ar.transposed_ready)
 
         def weights_after_data():
             ev = torch.cuda.Event()
