@@ -72,13 +72,13 @@ inline GemmProb dgrad(const void* dy, int M, int N, const void* w, int Kw, void*
 // so that every workgroup runs about the same number of 64-row contraction steps and the whole launch
 // has about ksplit_target() workgroups: small outputs then see a 10-20-way split (low atomic contention)
 // instead of one sized to fill the chip on their own.
-inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st, int lds_pad = 0) {
+inline int launch_wgrads(GemmProb* probs, int np, hipStream_t st, int lds_pad = 0, int target_blocks = 0) {
   long work = 0;
   for (int i = 0; i < np; ++i) {
     long tiles = ((probs[i].Pn + 127) / 128) * (long)((probs[i].Qn + 127) / 128);
     work += tiles * ((probs[i].K + 63) / 64);
   }
-  int target = ksplit_target() * 4;
+  int target = target_blocks > 0 ? target_blocks : ksplit_target() * 4;
   long iters = (work + target - 1) / target;
   if (iters < 4) iters = 4;
   for (int i = 0; i < np; ++i) {
@@ -646,7 +646,11 @@ int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts*
   probs[6] = wgrad(w->dqkv, M, 3 * D, a->x, D, g->w_qkv, g->b_qkv);
   // One workgroup per CU: the small, register-heavy kernels of the decoder's data pass (the row epilogue of the
   // split feed-forward block above all) run next to this launch and would otherwise wait for its grid to drain.
-  return launch_wgrads(probs, 7, (hipStream_t)stream_, 20000);
+  // ... and with few of them (80 instead of the usual ~512, each walking more of the 4032 rows): the launch then takes
+  // most of a layer's data pass but leaves two thirds of the CUs to it (8.27 -> 8.18 ms per training step; 32: 8.25,
+  // 16: 8.55).  Environment: MMST_DEC_WGRAD_BLOCKS.
+  static const int target = [] { const char* e = getenv("MMST_DEC_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 80; }();
+  return launch_wgrads(probs, 7, (hipStream_t)stream_, 20000, target);
 }
 
 int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
