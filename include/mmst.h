@@ -88,13 +88,14 @@ int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_
                                 const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
 int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                                    const mmst_enc_bwd* w, float drop_p, void* stream);
-/* Both halves on two streams, interleaved inside the layer: the feed-forward and out_proj weight gradients are
- * enqueued on wstream as soon as the feed-forward backward has been enqueued on stream (they then run beside the
- * attention backward of the same layer), the in_proj gradient after the rest of _data.  wstream is made to wait
- * for stream at both points; the caller joins the streams after the last layer.  Same results as _bwd. */
+/* Both halves on two streams in one call; wstream is made to wait for stream where needed (on the completion event
+ * of the kernel it depends on, not on a marker), the caller joins the streams after the last layer.
+ * interleave == 0: all parameter gradients on wstream after the data phase.  interleave != 0: the feed-forward and
+ * out_proj weight gradients are enqueued as soon as the feed-forward backward is (they then run beside the attention
+ * backward of the same layer), the in_proj gradient after the rest of _data.  Same results as _bwd. */
 int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                                   const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream,
-                                   void* wstream);
+                                   const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, int interleave,
+                                   void* stream, void* wstream);
 
 /* ---- one post-norm decoder layer == nn.TransformerDecoderLayer(d_model=128, nhead=16) (:539-541) ---- */
 typedef struct {

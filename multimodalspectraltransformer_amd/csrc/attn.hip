@@ -708,11 +708,11 @@ int launch_q(AttnBatch& b, hipStream_t stream) {
   }
   dim3 grid(total), block(64 * NWAVES);
   if (b.hd == 32) {
-    if (b.causal) hipLaunchKernelGGL((attn_q_kernel<32, true, BWD>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((attn_q_kernel<32, false, BWD>), grid, block, 0, stream, b);
+    if (b.causal) MMST_LAUNCH((attn_q_kernel<32, true, BWD>), grid, block, 0, stream, b);
+    else MMST_LAUNCH((attn_q_kernel<32, false, BWD>), grid, block, 0, stream, b);
   } else {
-    if (b.causal) hipLaunchKernelGGL((attn_q_kernel<8, true, BWD>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((attn_q_kernel<8, false, BWD>), grid, block, 0, stream, b);
+    if (b.causal) MMST_LAUNCH((attn_q_kernel<8, true, BWD>), grid, block, 0, stream, b);
+    else MMST_LAUNCH((attn_q_kernel<8, false, BWD>), grid, block, 0, stream, b);
   }
   MMST_CHECK_LAUNCH();
   return MMST_OK;

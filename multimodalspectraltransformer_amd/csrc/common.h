@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of the spectral-transformer path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef __bf16 bf16;
@@ -16,6 +17,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MMST_OK 0
 #define MMST_ERR_ARG (-1)
 #define MMST_ERR_LAUNCH (-2)
+
+// A completion event for the NEXT kernel launched through MMST_LAUNCH on this thread.  It is bound to that kernel's own
+// dispatch (hipExtLaunchKernelGGL), so another stream can wait for the kernel without a marker packet on the
+// launching stream: a separate hipEventRecord there holds the following kernel up for ~6 us.
+extern thread_local hipEvent_t mmst_armed_stop_event;   // defined in gemm.hip
+#define MMST_LAUNCH(kernel, grid, block, shmem, stream, ...)                                            \
+  do {                                                                                                   \
+    hipEvent_t ev__ = mmst_armed_stop_event;                                                             \
+    mmst_armed_stop_event = nullptr;                                                                     \
+    if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev__, 0, __VA_ARGS__);  \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
+  } while (0)
 
 #define MMST_CHECK_LAUNCH()                         \
   do {                                              \

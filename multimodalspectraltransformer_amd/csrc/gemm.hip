@@ -437,9 +437,9 @@ int wgrad_lds_pad() {
 template <int EPI, int NW>
 int dispatch_nw(const GemmBatch& b, bool pt, bool qt, int grid, hipStream_t s) {
   const int dyn = EPI == EPI_ATOMIC ? (b.lds_pad > wgrad_lds_pad() ? b.lds_pad : wgrad_lds_pad()) : 0;
-  if (!pt && !qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, false, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
-  else if (!pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, false, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
-  else if (pt && qt) hipLaunchKernelGGL((gemm_kernel<EPI, true, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
+  if (!pt && !qt) MMST_LAUNCH((gemm_kernel<EPI, false, false, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
+  else if (!pt && qt) MMST_LAUNCH((gemm_kernel<EPI, false, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
+  else if (pt && qt) MMST_LAUNCH((gemm_kernel<EPI, true, true, NW>), dim3(grid), dim3(NW * 64), dyn, s, b);
   else return MMST_ERR_ARG;
   return MMST_OK;
 }
@@ -471,6 +471,8 @@ void gemm_kernel_name(int epi, bool pt, bool qt, char* out, int cap) {
   else
     snprintf(out, cap, "gemm_kernel<%d, %s, %s, %d>", epi, pt ? "true" : "false", qt ? "true" : "false", gemm_waves(epi));
 }
+
+thread_local hipEvent_t mmst_armed_stop_event = nullptr;
 
 GemmTap g_gemm_tap = {-1, 0, 0, 0, 0, nullptr, nullptr, 0.0, 0.0};
 

@@ -190,6 +190,8 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
 
 namespace {
 
+hipEvent_t arm_completion_event();   // stream hand-off helpers, defined below
+
 inline bool enc_args_ok(int n, const void* p, const void* g, const void* a, const void* w, int nhead) {
   return n >= 1 && n <= MMST_MAX_GROUPS && p && g && a && w && (nhead == 16 || nhead == 4);
 }
@@ -219,7 +221,7 @@ int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const 
 
 // second part of the critical path: out_proj, attention and in_proj backward.  Leaves dqkv in w.
 int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const mmst_enc_bwd* w, int nhead, float drop_p,
-                 uint32_t seed, hipStream_t st) {
+                 uint32_t seed, hipStream_t st, hipEvent_t* done = nullptr) {
   const int hd = D / nhead;
   GemmBatch gb;
   gb.n = n;
@@ -260,6 +262,7 @@ int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const 
     }
     gb.p[i] = q;
   }
+  if (done) *done = arm_completion_event();   // completion event of the launch below
   return launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st);
 }
 
@@ -298,29 +301,44 @@ int enc_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, co
   return launch_wgrads(probs, np, st);
 }
 
-// `to` (if not null) waits for everything enqueued on `from` so far; the recorded event is handed back on request.
-// Events come from a per-device ring created on first
-// use (a wait holds the state its event had when the wait was enqueued, so a slot can be recorded again later).
-int stream_fork(hipStream_t from, hipStream_t to, hipEvent_t* recorded = nullptr) {
+// Events of a per-device ring created on first use (a wait holds the state its event had when the wait was
+// enqueued, so a slot can be used again later).
+hipEvent_t ring_event() {
   constexpr int MAX_DEV = 16, RING = 64;
   static hipEvent_t ring[MAX_DEV][RING];
   static bool made[MAX_DEV];
   static int next[MAX_DEV];
   static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return MMST_ERR_ARG;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   if (!made[dev]) {
     for (int i = 0; i < RING; ++i)
-      if (hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming) != hipSuccess) return MMST_ERR_LAUNCH;
+      if (hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
     made[dev] = true;
   }
   hipEvent_t ev = ring[dev][next[dev]];
   next[dev] = (next[dev] + 1) % RING;
+  return ev;
+}
+// `to` (if not null) waits for everything enqueued on `from` so far (a marker on `from`); the event is handed back
+// on request.
+int stream_fork(hipStream_t from, hipStream_t to, hipEvent_t* recorded = nullptr) {
+  hipEvent_t ev = ring_event();
+  if (!ev) return MMST_ERR_LAUNCH;
   if (hipEventRecord(ev, from) != hipSuccess) return MMST_ERR_LAUNCH;
   if (to && hipStreamWaitEvent(to, ev, 0) != hipSuccess) return MMST_ERR_LAUNCH;
   if (recorded) *recorded = ev;
   return MMST_OK;
+}
+// The next kernel launched through MMST_LAUNCH carries the returned event as its completion event (no marker).
+hipEvent_t arm_completion_event() {
+  hipEvent_t ev = ring_event();
+  mmst_armed_stop_event = ev;
+  return ev;
+}
+int wait_for(hipStream_t to, hipEvent_t ev) {
+  return (ev && hipStreamWaitEvent(to, ev, 0) == hipSuccess) ? MMST_OK : MMST_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -343,27 +361,26 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_e
   return enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY | WG_LATE, (hipStream_t)stream_);
 }
 
-// ---- both halves on two streams, interleaved: the feed-forward and out_proj weight gradients (nearly all of the
-// layer's weight-gradient work, HBM- and MFMA-heavy) start on wstream as soon as the feed-forward backward is
-// done and so run beside the attention backward (VALU-bound) of the same layer instead of beside the next
-// layer's feed-forward backward; the in_proj gradient follows when dqkv exists ----
+// ---- both halves on two streams.  interleave == 0: every parameter gradient on wstream once the data phase is
+// done (wstream waits for the completion event of its last kernel: no marker on `stream`).  interleave != 0: the
+// feed-forward and out_proj weight gradients (nearly all of the layer's weight-gradient work, HBM- and MFMA-heavy)
+// start on wstream as soon as the feed-forward backward is done and so run beside the attention backward
+// (VALU-bound) of the same layer instead of beside the next layer's feed-forward backward; the in_proj gradient
+// follows when dqkv exists ----
 int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                                   const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_,
-                                   void* wstream_) {
-  if (!enc_args_ok(n, p, g, a, w, nhead) || stream_ == wstream_) return MMST_ERR_ARG;
+                                   const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, int interleave,
+                                   void* stream_, void* wstream_) {
+  if (!enc_args_ok(n, p, g, a, w, nhead) || !wstream_ || stream_ == wstream_) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
+  hipEvent_t done = nullptr;
   RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, st));
-  RUN(stream_fork(st, wst));
-  RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
-  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st));
-  RUN(stream_fork(st, wst));
-  return enc_bwd_weights(n, p, g, a, w, drop_p, WG_LATE, wst);
-}
-
-int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
-                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
-  RUN(mmst_encoder_layer_bwd_data(n, p, g, a, w, nhead, drop_p, seed, stream_));
-  return mmst_encoder_layer_bwd_weights(n, p, g, a, w, drop_p, stream_);
+  if (interleave) {
+    RUN(stream_fork(st, wst));
+    RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
+  }
+  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, &done));
+  RUN(wait_for(wst, done));
+  return enc_bwd_weights(n, p, g, a, w, drop_p, interleave ? WG_LATE : (WG_EARLY | WG_LATE), wst);
 }
 
 int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,
@@ -525,7 +542,8 @@ namespace {
 // to wst: the next decoder layer does not wait for it.  join: st waits for that dmem update at its end (the
 // caller is about to read dmem on st).
 int dec_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a, const mmst_dec_bwd* w,
-                 int nhead, float drop_p, uint32_t seed, hipStream_t st, hipStream_t wst, bool join) {
+                 int nhead, float drop_p, uint32_t seed, hipStream_t st, hipStream_t wst, bool join,
+                 hipEvent_t* done = nullptr) {
   if (!p || !g || !a || !w || nhead != 16) return MMST_ERR_ARG;
   const int hd = D / nhead, M = a->B * a->T, ML = a->B * a->L;
   const bool dr = drop_p > 0.f;
@@ -563,11 +581,12 @@ int dec_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_d
     q.B = a->B; q.H = nhead; q.Tq = a->T; q.Sk = a->L; q.seed = seed + 2;
   }
   if (wst && !w->delta2) return MMST_ERR_ARG;
+  hipEvent_t q_done = wst ? arm_completion_event() : nullptr;   // of the dQ kernel: it also leaves delta
   RUN(launch_attn_bwd_q(ab, st));
   hipEvent_t dmem_done = nullptr;
   {
     hipStream_t kst = wst ? wst : st;
-    if (wst) RUN(stream_fork(st, wst));
+    if (wst) RUN(wait_for(wst, q_done));
     RUN(launch_attn_bwd_kv(ab, kst));
     GemmBatch gk;
     gk.n = 1;
@@ -612,6 +631,7 @@ int dec_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_d
       q.drop_p = drop_p; q.seed = w->prev_seed + 5;
     }
     gb.p[0] = q;
+    if (done) *done = arm_completion_event();
     RUN(launch_gemm(gb, prev ? EPI_LNBWD : EPI_BIAS, false, true, st));
   }
   if (dmem_done && hipStreamWaitEvent(st, dmem_done, 0) != hipSuccess) return MMST_ERR_LAUNCH;
@@ -667,8 +687,9 @@ int mmst_decoder_layer_bwd_streams(const mmst_dec_params* p, const mmst_dec_grad
                                    void* stream_, void* wstream_) {
   if (!wstream_ || stream_ == wstream_) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
-  RUN(dec_bwd_data(p, g, a, w, nhead, drop_p, seed, st, wst, join_dmem != 0));
-  RUN(stream_fork(st, wst));
+  hipEvent_t done = nullptr;
+  RUN(dec_bwd_data(p, g, a, w, nhead, drop_p, seed, st, wst, join_dmem != 0, &done));
+  RUN(wait_for(wst, done));
   return mmst_decoder_layer_bwd_weights(g, a, w, drop_p, wstream_);
 }
 

@@ -666,15 +666,9 @@ class Engine:
             ws.wait_event(ev)
 
         def encoder_layer_bwd(n, p, g, a, w, heads, seed):
-            if self.interleave_wgrads:
-                L.check(lib.mmst_encoder_layer_bwd_streams(n, p, g, a, w, heads, C.c_float(p_drop), C.c_uint32(seed),
-                                                           st, wst), "mmst_encoder_layer_bwd_streams")
-                return
-            L.check(lib.mmst_encoder_layer_bwd_data(n, p, g, a, w, heads, C.c_float(p_drop), C.c_uint32(seed), st),
-                    "mmst_encoder_layer_bwd_data")
-            weights_after_data()
-            L.check(lib.mmst_encoder_layer_bwd_weights(n, p, g, a, w, C.c_float(p_drop), wst),
-                    "mmst_encoder_layer_bwd_weights")
+            L.check(lib.mmst_encoder_layer_bwd_streams(n, p, g, a, w, heads, C.c_float(p_drop), C.c_uint32(seed),
+                                                       1 if self.interleave_wgrads else 0, st, wst),
+                    "mmst_encoder_layer_bwd_streams")
 
         if not skip_decoder:
             # vocabulary projection
