@@ -1,0 +1,196 @@
+"""mmst_decoder_stack_step (one new target position through every decoder layer in one launch) through the C ABI
+against a plain PyTorch fp32 evaluation of the same step on the same bf16 weights and caches, and against
+mmst_decoder_layer_step.  The kernel rounds the row to bf16 between stages (as the training kernels do), so the
+stated tolerance is max-abs 6e-2 on LayerNorm outputs (6e-2 + 2 % on logits) and cosine >= 0.999."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D, FF, NH, HD = 128, 2048, 16, 8
+
+if torch.cuda.is_available():
+    from multimodalspectraltransformer_amd import _lib as L
+
+
+def _layer_params(gen, dev):
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=gen, device=dev) * sc  # noqa: E731
+    w = dict(w_qkv=r(3 * D, D, sc=0.09), w_o=r(D, D, sc=0.09), w_cqkv=r(3 * D, D, sc=0.09), w_co=r(D, D, sc=0.09),
+             w_1=r(FF, D, sc=0.09), w_2=r(D, FF, sc=0.02))
+    w = {k: v.bfloat16() for k, v in w.items()}
+    f = dict(b_qkv=r(3 * D, sc=0.1), b_o=r(D, sc=0.1), b_cqkv=r(3 * D, sc=0.1), b_co=r(D, sc=0.1), b_1=r(FF, sc=0.1),
+             b_2=r(D, sc=0.1))
+    for i in (1, 2, 3):
+        f[f"g{i}"] = 1.0 + r(D, sc=0.1)
+        f[f"be{i}"] = r(D, sc=0.1)
+    return {**w, **f}
+
+
+def _ln(z, g, b):
+    mu = z.mean(-1, keepdim=True)
+    var = ((z - mu) ** 2).mean(-1, keepdim=True)
+    return (z - mu) * torch.rsqrt(var + 1e-5) * g + b
+
+
+def _attend(q, K, V, bias):
+    """q [B][128], K/V [B][S][128] fp32, bias [B][S] or None -> [B][128]"""
+    B, S = K.shape[0], K.shape[1]
+    qh = q.view(B, NH, 1, HD)
+    Kh = K.view(B, S, NH, HD).permute(0, 2, 1, 3)
+    Vh = V.view(B, S, NH, HD).permute(0, 2, 1, 3)
+    sc = (qh @ Kh.transpose(2, 3)) / math.sqrt(HD)
+    if bias is not None:
+        sc = sc + bias.view(B, 1, 1, S)
+    return (torch.softmax(sc, dim=-1) @ Vh).reshape(B, D)
+
+
+def _reference_step(layers, x, caches, pos, kvc, bias, group):
+    """fp32 evaluation; caches[l] [B][cap][384] are read for positions < pos, the new row is returned per layer."""
+    B = x.shape[0]
+    rows = []
+    for l, p in enumerate(layers):
+        f = {k: v.float() for k, v in p.items()}
+        qkv = x @ f["w_qkv"].t() + f["b_qkv"]
+        rows.append(qkv)
+        c = caches[l].float()
+        K = torch.cat([c[:, :pos, D:2 * D], qkv[:, None, D:2 * D]], 1)
+        V = torch.cat([c[:, :pos, 2 * D:], qkv[:, None, 2 * D:]], 1)
+        a = _attend(qkv[:, :D], K, V, None)
+        x1 = _ln(x + a @ f["w_o"].t() + f["b_o"], f["g1"], f["be1"])
+        qc = x1 @ f["w_cqkv"][:D].t() + f["b_cqkv"][:D]
+        mem = kvc[l].float().repeat_interleave(group, dim=0)
+        mb = bias.repeat_interleave(group, dim=0) if bias is not None else None
+        a2 = _attend(qc, mem[:, :, :D], mem[:, :, D:], mb)
+        x2 = _ln(x1 + a2 @ f["w_co"].t() + f["b_co"], f["g2"], f["be2"])
+        h = torch.relu(x2 @ f["w_1"].t() + f["b_1"])
+        x = _ln(x2 + h @ f["w_2"].t() + f["b_2"], f["g3"], f["be3"])
+    return x, rows
+
+
+def _params_array(layers):
+    arr = (L.DecParams * len(layers))()
+    for l, p in enumerate(layers):
+        for k, v in p.items():
+            setattr(arr[l], k, v.data_ptr())
+    return arr
+
+
+@pytest.mark.parametrize("B,group,Lm,cap,pos,nl,masked", [
+    (3, 1, 70, 16, 0, 2, False),      # first position: a single key
+    (3, 1, 70, 16, 5, 2, True),
+    (4, 2, 582, 140, 63, 3, True),    # two sequences per memory block (beams), benchmark memory length
+    (1, 1, 9, 200, 131, 1, False),    # more cached positions than one batch of key loads covers
+    (64, 1, 130, 64, 17, 6, True),
+])
+def test_stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked):
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(1000 + B + pos)
+    layers = [_layer_params(gen, dev) for _ in range(nl)]
+    r = lambda *s: torch.randn(*s, generator=gen, device=dev)  # noqa: E731
+    V, VP = 43, 64
+    embed, pos_row = r(V, D) * 0.5, r(D) * 0.5
+    tok = torch.randint(0, V, (B,), generator=gen, device=dev)
+    w_out = torch.zeros(VP, D, device=dev)
+    w_out[:V] = r(V, D) * 0.2
+    w_out = w_out.bfloat16()
+    b_out = torch.zeros(VP, device=dev)
+    b_out[:V] = r(V) * 0.1
+    caches = [(r(B, cap, 3 * D) * 0.7).bfloat16() for _ in range(nl)]
+    kvc = [(r(B // group, Lm, 2 * D) * 0.7).bfloat16() for _ in range(nl)]
+    bias = None
+    if masked:
+        bias = torch.zeros(B // group, Lm, device=dev)
+        bias[:, Lm // 2:Lm // 2 + 3] = float("-inf")
+        bias[0, -1] = float("-inf")
+    x0 = (embed[tok] + pos_row).bfloat16().float()
+    want, rows = _reference_step(layers, x0, caches, pos, kvc, bias, group)
+    want_logits = want @ w_out.float().t() + b_out
+
+    y = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+    logits = torch.full((B, VP), 7.0, device=dev)
+    nxt = torch.full((B,), -1, dtype=torch.long, device=dev)
+    prob = torch.zeros(B, device=dev)
+    mine = [c.clone() for c in caches]
+    s = L.DecStackStep()
+    s.tok, s.embed, s.pos_row, s.y = tok.data_ptr(), embed.data_ptr(), pos_row.data_ptr(), y.data_ptr()
+    for l in range(nl):
+        s.qkv_cache[l], s.kvc[l] = mine[l].data_ptr(), kvc[l].data_ptr()
+    s.mem_bias = bias.data_ptr() if bias is not None else None
+    s.w_out, s.b_out, s.logits, s.ld_logits, s.n_out = w_out.data_ptr(), b_out.data_ptr(), logits.data_ptr(), VP, VP
+    s.next_tok, s.next_prob, s.temperature, s.V = nxt.data_ptr(), prob.data_ptr(), 0.7, V
+    s.B, s.pos, s.cap, s.L, s.kv_group = B, pos, cap, Lm, group
+    L.check(L.lib().mmst_decoder_stack_step(nl, _params_array(layers), C.byref(s), NH, L.stream_ptr()), "stack_step")
+    torch.cuda.synchronize()
+
+    got = y.float()
+    assert float((got - want).abs().max()) < 6e-2
+    assert float(torch.nn.functional.cosine_similarity(got, want, dim=1).min()) > 0.999
+    lerr = (logits[:, :V] - want_logits[:, :V]).abs()
+    assert bool((lerr < 6e-2 + 2e-2 * want_logits[:, :V].abs()).all()), float(lerr.max())   # logits reach |6|
+    assert float(logits[:, V:].abs().max()) == 0.0          # zero-padded rows of the projection
+    for l in range(nl):   # the new cache row, and nothing else, was written
+        assert float((mine[l][:, pos].float() - rows[l]).abs().max()) < (4e-2 if l == 0 else 8e-2)
+        keep = torch.ones(cap, dtype=torch.bool, device=dev)
+        keep[pos] = False
+        assert torch.equal(mine[l][:, keep], caches[l][:, keep])
+    # greedy choice on the kernel's own logits: first maximum, softmax(logits / T) probability
+    z = logits[:, :V] / 0.7
+    assert torch.equal(nxt, z.argmax(dim=1))
+    assert float((prob - torch.softmax(z, dim=1).max(dim=1).values).abs().max()) < 1e-5
+
+
+def test_stack_step_equals_layer_steps():
+    """Same caches, same inputs: one launch for the whole stack against one mmst_decoder_layer_step per layer
+    (GEMM / attention tile kernels); both round to bf16 at the same points, so they agree to bf16 noise."""
+    dev, B, Lm, cap, pos, nl = "cuda", 8, 193, 32, 11, 2
+    gen = torch.Generator(device=dev).manual_seed(5)
+    layers = [_layer_params(gen, dev) for _ in range(nl)]
+    r = lambda *s: torch.randn(*s, generator=gen, device=dev)  # noqa: E731
+    x = (r(B, D) * 0.8).bfloat16()
+    caches = [(r(B, cap, 3 * D) * 0.7).bfloat16() for _ in range(nl)]
+    kvc = [(r(B, Lm, 2 * D) * 0.7).bfloat16() for _ in range(nl)]
+    bias = torch.zeros(B, Lm, device=dev)
+    bias[:, 100:] = float("-inf")
+    params = _params_array(layers)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    # per-layer path
+    c1 = [c.clone() for c in caches]
+    rows = [x.clone(), torch.zeros(B, D, **bf)]
+    attn, x1, qc, x2 = (torch.zeros(B, D, **bf) for _ in range(4))
+    h, lse, ws = torch.zeros(B, FF, **bf), torch.zeros(B, 16, device=dev), torch.zeros(8, B, D, device=dev)
+    for l in range(nl):
+        st = L.DecStep()
+        st.x, st.y = rows[l % 2].data_ptr(), rows[(l + 1) % 2].data_ptr()
+        st.qkv_cache, st.kvc, st.mem_bias = c1[l].data_ptr(), kvc[l].data_ptr(), bias.data_ptr()
+        st.attn, st.x1, st.qc, st.x2, st.h, st.lse = (t.data_ptr() for t in (attn, x1, qc, x2, h, lse))
+        st.ffn_ws = ws.data_ptr()
+        st.B, st.pos, st.cap, st.L = B, pos, cap, Lm
+        L.check(L.lib().mmst_decoder_layer_step(C.byref(params[l]), C.byref(st), NH, L.stream_ptr()), "layer_step")
+    want = rows[nl % 2].float()
+    # one launch
+    c2 = [c.clone() for c in caches]
+    y = torch.zeros(B, D, **bf)
+    s = L.DecStackStep()
+    s.x, s.y, s.mem_bias = x.data_ptr(), y.data_ptr(), bias.data_ptr()
+    for l in range(nl):
+        s.qkv_cache[l], s.kvc[l] = c2[l].data_ptr(), kvc[l].data_ptr()
+    s.B, s.pos, s.cap, s.L = B, pos, cap, Lm
+    L.check(L.lib().mmst_decoder_stack_step(nl, params, C.byref(s), NH, L.stream_ptr()), "stack_step")
+    torch.cuda.synchronize()
+    assert float((y.float() - want).abs().max()) < 5e-2
+    for l in range(nl):
+        assert float((c1[l].float() - c2[l].float()).abs().max()) < (2e-2 if l == 0 else 5e-2)   # l = 0: one bf16 ulp
+
+
+def test_stack_step_rejects_bad_arguments():
+    s = L.DecStackStep()
+    p = (L.DecParams * 1)()
+    lib = L.lib()
+    assert lib.mmst_decoder_stack_step(1, p, C.byref(s), NH, None) != 0          # empty step
+    s.B, s.pos, s.cap, s.L = 2, 4, 4, 8                                             # pos beyond the cache
+    assert lib.mmst_decoder_stack_step(1, p, C.byref(s), NH, None) != 0
+    assert lib.mmst_decoder_stack_step(9, p, C.byref(s), NH, None) != 0          # too many layers
+    assert lib.mmst_decoder_stack_step(1, p, C.byref(s), 4, None) != 0           # head count
