@@ -383,6 +383,12 @@ int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_e
   return enc_bwd_weights(n, p, g, a, w, drop_p, interleave ? WG_LATE : (WG_EARLY | WG_LATE), wst);
 }
 
+int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
+                           const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
+  RUN(mmst_encoder_layer_bwd_data(n, p, g, a, w, nhead, drop_p, seed, stream_));
+  return mmst_encoder_layer_bwd_weights(n, p, g, a, w, drop_p, stream_);
+}
+
 int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,
                        const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float drop_p,
                        uint32_t seed, void* stream_) {
