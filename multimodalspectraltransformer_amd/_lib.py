@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmst.so")
+LIB_PATH = os.environ.get("MMST_LIB") or os.path.join(_HERE, "libmmst.so")   # MMST_LIB: another build of the library
 
 EPI_BIAS, EPI_DRELU, EPI_LN, EPI_LNBWD, EPI_ATOMIC = range(5)
 GF_RELU, GF_OUT_F32 = 1, 2
