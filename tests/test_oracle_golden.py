@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import mmt_oracle as O
-from tests.util import GOLDEN, digest, digest_close, load_golden
+from tests.util import apply_trained, GOLDEN, digest, digest_close, load_golden
 
 CASES = [
     ("fwd_c2_L2", "1H_HSQC_COSY_IR_MF_MW"),
@@ -83,17 +83,58 @@ def test_adamw_two_steps():
             digest_close(digest(params[k[5:]]), g[k], 1e-5, 1e-6)
 
 
-@pytest.mark.parametrize("name,mode", [("greedy_c2_L2", "1H_HSQC_COSY_IR_MF_MW"), ("greedy_c1_L2", "1H")])
+def test_full_size_step_matches_reference():
+    """The benchmark configuration at its real size (64 molecules, 6 + 6 layers) against the reference's own step:
+    loss, per-molecule losses, logits digest, every parameter gradient, one AdamW step."""
+    g = load_golden("step_c2_full")
+    cfg, sd, batch = _setup(g, "1H_HSQC_COSY_IR_MF_MW")
+    assert int(g["B"]) == 64 and int(g["nl"]) == 6
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, logits, fp, memory, mask = O.training_forward(params, cfg, batch)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert tuple(logits.shape) == tuple(g["logits_shape"])
+    digest_close(digest(logits, 4096), g["logits_digest"], 1e-4, 2e-5)
+    V = logits.shape[-1]
+    trg = batch["trg_enc_SMI"].t()
+    per_pos = torch.nn.functional.cross_entropy(logits.detach().reshape(-1, V), trg[1:, :].reshape(-1), reduction="none")
+    np.testing.assert_allclose(per_pos.reshape(logits.shape[0], -1).mean(0).numpy(), g["loss_per_molecule"], atol=2e-5)
+    np.testing.assert_allclose(fp.detach().numpy(), g["fingerprint"], atol=2e-5, rtol=1e-4)
+    nograd = set(str(k) for k in g["nograd"])
+    checked = 0
+    for k, p in params.items():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        digest_close(digest(p.grad), g["grad/" + k], 2e-3, 1e-7)
+        checked += 1
+    assert checked > 400
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+    with torch.no_grad():
+        O.adamw_step(params, {k: p.grad for k, p in params.items()}, m, v, 1, cfg["lr_pretraining"])
+    for k in g.files:
+        if k.startswith("post/"):
+            digest_close(digest(params[k[5:]]), g[k], 1e-5, 1e-6)
+
+
+GREEDY = [("greedy_c2_L2", "1H_HSQC_COSY_IR_MF_MW"), ("greedy_c1_L2", "1H"), ("greedy_c2_L6", "1H_HSQC_COSY_IR_MF_MW")]
+
+
+@pytest.mark.parametrize("name,mode", GREEDY)
 def test_greedy_tokens_identical(name, mode):
+    """Reference greedy_sequence on a model with confident decisions (fitted readout, see make_golden.train_readout):
+    tokens, probabilities and SMILES strings identical end to end, stop rule included."""
     g = load_golden(name)
     nl = int(g["nl"])
     cfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
-    sd = O.make_state_dict(cfg, int(g["wseed"]), logit_gain=float(g["gain"]))
+    sd = apply_trained(O.make_state_dict(cfg, int(g["wseed"]), logit_gain=float(g["gain"])), g)
     batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), mode)
     with torch.no_grad():
         memory, _, mask, fp = O.forward(sd, cfg, batch, None)
         toks, probs, margins = O.greedy_sequence(sd, cfg, memory, mask)
     assert np.array_equal(toks.numpy(), g["tokens"])
+    assert float(g["margins"].min()) > 2.0 and len(toks) < cfg["max_len"]   # separated decisions; stopped on all-<PAD>
     np.testing.assert_allclose(probs.numpy(), g["probs"], atol=1e-5)
     itos = json.load(open(os.path.join(GOLDEN, "itos.json")))
     assert O.tensor_to_smiles(toks, itos) == [str(s) for s in g["smiles"]]

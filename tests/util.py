@@ -10,6 +10,18 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+def apply_trained(sd, g):
+    """Fixtures of a fitted model (the greedy-decode cases) carry the few fitted tensors as 'trained/<key>';
+    every other tensor is regenerated from the seed."""
+    import torch
+    for k in g.files:
+        if k.startswith("trained/"):
+            key = k[len("trained/"):]
+            assert tuple(sd[key].shape) == g[k].shape, key
+            sd[key] = torch.from_numpy(np.array(g[k], dtype=np.float32))
+    return sd
+
+
 def digest(t, n=96):
     """Same digest as oracle/make_golden.py: [sum, sum|x|, sum x^2] + n strided samples."""
     a = np.asarray(t.detach().cpu().float().numpy() if hasattr(t, "detach") else t, dtype=np.float64).reshape(-1)
