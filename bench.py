@@ -4,7 +4,12 @@ MultimodalTransformer (config_V8.json architecture, training_mode 1H_HSQC_COSY_I
 GPU), on N MI355X of one node, one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W        (starts the N ranks itself, one process per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+--gpus N has the meaning of the reference's Trainer(gpus=N, accelerator='ddp') (MT_functions_v15_4.py:139-151): one
+call, N processes, per-rank batch = --batch.  A rank count that differs from --gpus is an error, never a silent
+single-GPU measurement.
 """
 import argparse
 import ctypes as C
@@ -64,6 +69,21 @@ def pmc_traffic(kernel):
     return None
 
 
+def launch_ranks(n):
+    """Start n ranks of this script (torch.distributed.run, one process per GPU) and pass their output through.
+    Called before anything in this process has touched the GPU; the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,9 +95,14 @@ def main():
     ap.add_argument("--gen", action="store_true", help="also run the in-training greedy generation (secondary metric)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); run `python bench.py --gpus "
+                 f"{args.gpus}` (it starts the ranks itself) or give torch.distributed.run --nproc-per-node {args.gpus}")
     # MMST_BENCH_ONE_GPU=1 is a REHEARSAL of the multi-rank code path on a single-GPU box (all ranks share
     # cuda:0 and reduce through gloo); its numbers mean nothing.  Real runs: one rank per GPU over RCCL.
     rehearsal = os.environ.get("MMST_BENCH_ONE_GPU") == "1"
@@ -86,6 +111,8 @@ def main():
         local_rank = 0
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         faulthandler.dump_traceback_later(100, exit=True)   # a rehearsal that hangs says where
+    if not rehearsal and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
@@ -160,7 +187,8 @@ def main():
     if rank == 0:
         mols = world * args.batch * args.steps
         res = {"metric": "molecules/sec training step (4-modality, seq<=128)", "value": mols / dt,
-               "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "molecules/s", "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+               "collective": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1000 * dt / args.steps, "host_enqueue_ms_per_step": 1000 * t_enqueue / args.steps,
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -122,6 +122,8 @@ typedef struct {
   int kv_ready; /* nonzero: kvc already holds this layer's K/V projection of mem (decode loops reuse it) */
   float* ffn_ws; /* optional fp32 workspace [8][B*T][128]: lets the feed-forward block of a SHORT sequence split its
                     hidden dimension over up to 8 workgroups per row tile (NULL: no split) */
+  int no_causal; /* nonzero: self-attention without the causal mask (nn.TransformerDecoder called with tgt_mask=None);
+                    0, the default, is the reference's generate_square_subsequent_mask (:794-800, :962) */
 } mmst_dec_acts;
 
 /* ---- one decoder layer for ONE new target position with cached keys/values (inference) ----

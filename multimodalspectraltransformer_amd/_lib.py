@@ -151,7 +151,7 @@ class DecGrads(C.Structure):
 class DecActs(C.Structure):
     _fields_ = _ptrs("x", "y", "mem", "mem_bias", "qkv", "attn1", "lse1", "z1", "st1", "x1", "qc", "kvc", "attn2",
                      "lse2", "z2", "st2", "x2", "h", "z3", "st3") + [
-        ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int), ("ffn_ws", C.c_void_p)]
+        ("B", C.c_int), ("T", C.c_int), ("L", C.c_int), ("kv_ready", C.c_int), ("ffn_ws", C.c_void_p), ("no_causal", C.c_int)]
 
 
 class DecStep(C.Structure):

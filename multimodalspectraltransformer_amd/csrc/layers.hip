@@ -420,7 +420,7 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
   gb.p[0] = fwd_linear(a->x, M, D, p->w_qkv, 3 * D, p->b_qkv, a->qkv);
   RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
   memset(&ab, 0, sizeof(ab));
-  ab.n = 1; ab.hd = hd; ab.causal = 1; ab.drop_p = drop_p;
+  ab.n = 1; ab.hd = hd; ab.causal = a->no_causal ? 0 : 1; ab.drop_p = drop_p;
   {
     AttnProb& q = ab.p[0];
     const bf16* qkv = (const bf16*)a->qkv;
@@ -614,7 +614,7 @@ int dec_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_d
   // self-attention block
   gb.p[0] = dgrad(dzd1, M, D, p->w_o, D, w->da);
   RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
-  ab.causal = 1;
+  ab.causal = a->no_causal ? 0 : 1;
   {
     AttnProb& q = ab.p[0];
     memset(&q, 0, sizeof(q));

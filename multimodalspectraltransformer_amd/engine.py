@@ -101,6 +101,7 @@ class Arena:
             p.data = view
         self.named = named
         self.shadow_stale = True
+        self.weights_serial = 0        # counts rewrites of the bf16 weight copy (caches of projected tensors key on it)
         self.transposed_ready = None   # event after the last refresh of PbT on another stream than the caller's
 
     def owns(self, model):
@@ -140,6 +141,7 @@ class Arena:
                                        self.total, self.total, L.stream_ptr()), "mmst_cast_bf16")
         self.refresh_transposed()
         self.shadow_stale = False
+        self.weights_serial += 1
 
     def active_keys(self, mode):
         """Parameters that receive a gradient in this training_mode (the reference leaves the others at
@@ -190,6 +192,28 @@ class Arena:
             else:
                 ranges.append([lo, hi])
         return [tuple(r) for r in ranges]
+
+    def prepare_grads(self, mode):
+        """torch.autograd semantics for the flat gradient buffer before a backward pass ACCUMULATES into it: a
+        parameter whose .grad is None (optimizer.zero_grad() sets it to None by default) starts from zero, one whose
+        .grad already is its slice of the buffer keeps accumulating, a foreign .grad tensor is taken over."""
+        act = self.active_keys(mode)
+        if all(self.named[k].grad is None for k in act):
+            for lo, hi in self.active_ranges(mode):
+                self.G[lo:hi].zero_()
+        else:
+            for k in act:
+                p, view = self.named[k], self.grad_view(k)
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+        self.attach_grads(mode)
+
+    def param_signature(self):
+        """Changes whenever a torch optimizer (or any in-place operation through the nn.Parameters) has written
+        the fp32 weights since the last call."""
+        return sum(p._version for p in self.named.values())
 
     def attach_grads(self, mode=None):
         act = set(self.active_keys(mode)) if mode is not None else None
@@ -496,8 +520,16 @@ class Engine:
             self.device = device
             self.arena = Arena(self.model, device)
             self.plans = {}
-        if self.arena.shadow_stale or self.model.training and self.model._external_optimizer:
-            self.arena.refresh_shadow()
+        ar = self.arena
+        if self.model._external_optimizer:
+            # a torch optimizer updates the fp32 weights in place, in train or eval mode alike: refresh the bf16
+            # copies whenever the parameters' version counters have moved (the fused AdamW keeps them itself)
+            sig = ar.param_signature()
+            if sig != getattr(ar, "_seen_signature", None):
+                ar.shadow_stale = True
+                ar._seen_signature = sig
+        if ar.shadow_stale:
+            ar.refresh_shadow()
 
     def plan(self, B, T, mode):
         key = (B, T, mode)
@@ -573,6 +605,7 @@ class Engine:
         m = self.model
         p_drop = LAYER_DROPOUT if train else 0.0
         G_, s, keep, glob_bool = self._embed_structs(pl, batch)
+        pl.encode_serial = getattr(pl, "encode_serial", 0) + 1
         pl.embed_structs = (G_, s, keep)
         pl.mask_is_bool = glob_bool
         L.check(lib.mmst_embed_fwd(pl.n_groups, G_, C.byref(s), st), "mmst_embed_fwd")

@@ -125,7 +125,8 @@ def _cross_kv(model, pl):
     ops.gemm(groups, L.EPI_BIAS)
 
 
-def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None):
+def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None,
+                        keep_logits=None):
     """Decode loop with cached keys/values: per token one new row through the decoder.
 
     With MMST_DECODE_GRAPH=1 greedy decoding replays one hipGraph per target position (captured on first use, kept
@@ -156,8 +157,11 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
 
     def enqueue(pos, select):
         if fused:
+            if keep_logits is not None:   # this position's logits go to row `pos` of the caller's [max_len][B][64] buffer
+                stt.stack.logits = keep_logits[pos].data_ptr()
             stt.stack_step(tok[pos].data_ptr(), pe, pos, tok[pos + 1].data_ptr() if select else None,
                            prob[pos].data_ptr() if select else None, temperature)
+            stt.stack.logits = stt.logits.data_ptr()
             return
         L.check(lib.mmst_trg_embed_fwd(C.c_void_p(tok[pos].data_ptr()), B, C.c_void_p(emb), C.c_void_p(pe + 4 * D * pos),
                                        C.c_void_p(stt.rows[0].data_ptr()), B, 1, C.c_float(0.0), C.c_uint32(0), st()),
@@ -171,6 +175,8 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
             L.check(lib.mmst_greedy_select(C.c_void_p(stt.logits.data_ptr()), VPAD, model.out_size, B, 1,
                                            C.c_float(float(temperature)), C.c_void_p(tok[pos + 1].data_ptr()),
                                            C.c_void_p(prob[pos].data_ptr()), st()), "mmst_greedy_select")
+        if keep_logits is not None:
+            keep_logits[pos].copy_(stt.logits)
 
     steps = 0
     for t in range(1, max_len + 1):
@@ -201,12 +207,16 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
     return tok[:steps + 1].clone(), prob[:steps].clone()
 
 
-def _decode_plan(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None, cached=None):
-    """Shared loop on an encoded plan.  Returns tokens (steps+1, B) incl. <SOS> and probs (steps, B)."""
+def _decode_plan(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None, cached=None,
+                 keep_logits=None):
+    """Shared loop on an encoded plan.  Returns tokens (steps+1, B) incl. <SOS> and probs (steps, B).
+    keep_logits: optional fp32 [max_len][B][64] buffer that receives every position's logits (cached path only)."""
     if cached is None:
         cached = os.environ.get("MMST_DECODE_CACHED", "1") != "0"
+    if keep_logits is not None and not cached:
+        raise L.MMSTError("keep_logits needs the cached decode")
     if cached:
-        return _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample, generator)
+        return _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample, generator, keep_logits)
     eng = model._engine
     B = pl.B
     lib, st = L.lib(), L.stream_ptr
@@ -236,8 +246,8 @@ def _decode_plan(model, pl, max_len, temperature, sos, early_stop, sample=False,
 
 
 def greedy_sequence(model, stoi, itos, memory, src_padding_mask, config):
-    """Reference signature.  `memory` must be the memory of the model's last run_model()/forward() call
-    (it is held in the plan buffers); tokens (steps, B) without <SOS> and probabilities with the first
+    """Reference signature.  `memory` must come from run_model() / MultimodalTransformer.forward() (it is held in
+    the plan buffers, see _plan_for); tokens (steps, B) without <SOS> and probabilities with the first
     row dropped, as validate_generate_MMT_v15_4.py:768-775 returns them."""
     pl = _plan_for(model, memory)
     toks, probs = _decode_plan(model, pl, config.max_len, config.temperature, stoi["<SOS>"], early_stop=True)
@@ -258,10 +268,42 @@ def multinomial_sequence(model, stoi, memory, src_padding_mask, config, generato
     return toks[1:], probs.transpose(0, 1)
 
 
-def generate_sequences(model, pl, config, stoi, itos, temperature=1):
-    """In-training generation (models_MMT_v15_4.py:1222-1297), greedy branch: no early stop, max_len steps."""
+def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=None, generator=None):
+    """In-training generation, TransformerMultiGPU._generate_sequences (models_MMT_v15_4.py:1222-1297), on an encoded
+    plan: max_len decode steps without early stop; returns the reference's (token tensor incl. <SOS>, SMILES list,
+    list of per-molecule confidence tensors).  config.sampling_method:
+      "greedy"      argmax decode (:1248-1256).
+      "multinomial" the reference only ever feeds the GREEDY tensor to the decoder (:1241) and never grows it in
+                    this mode, so every step samples from the distribution of position 0 given <SOS> alone (:1258-1264);
+                    one decoder position is computed and sampled max_len times.
+      "mix"         greedy decode; the multinomial tokens are sampled from the greedy-prefix distributions, and the
+                    MULTINOMIAL confidences are the ones cut to the greedy strings' lengths (:1294); combine_gen_sims
+                    then keeps the greedy result for every molecule (its except-branch needs Chem.MolFromSmiles to
+                    raise, which it does not for strings: it returns None).
+    """
     sos = stoi["<SOS>"] if stoi else 3
-    toks, probs = _decode_plan(model, pl, config.max_len, temperature, sos, early_stop=False)
+    max_len = int(max_len or config.max_len)
+    method = getattr(config, "sampling_method", "greedy")
+    if method not in ("greedy", "multinomial", "mix"):
+        raise ValueError(f"sampling_method {method!r}")
+    V = model.out_size
+    if method == "multinomial":
+        keep = torch.empty(1, pl.B, VPAD, dtype=torch.float32, device=model._engine.device)
+        _decode_plan(model, pl, 1, temperature, sos, early_stop=False, cached=True, keep_logits=keep)
+        p0 = torch.softmax(keep[0, :, :V] / temperature, dim=1)
+        nxt = torch.multinomial(p0, max_len, replacement=True, generator=generator)        # (B, max_len)
+        toks = torch.cat((torch.full((1, pl.B), sos, dtype=torch.long, device=nxt.device), nxt.t()), dim=0)
+        probs = p0.gather(1, nxt).t().contiguous()
+    else:
+        keep = None
+        if method == "mix":
+            keep = torch.empty(max_len, pl.B, VPAD, dtype=torch.float32, device=model._engine.device)
+        toks, probs = _decode_plan(model, pl, max_len, temperature, sos, early_stop=False,
+                                   cached=True if method == "mix" else None, keep_logits=keep)
+        if method == "mix":
+            p = torch.softmax(keep[:, :, :V] / temperature, dim=2)
+            nxt = torch.multinomial(p.reshape(-1, V), 1, generator=generator)
+            probs = p.reshape(-1, V).gather(1, nxt).reshape(max_len, pl.B)
     smiles, conf = (None, None)
     if itos:
         smiles, conf = hf.tensor_to_smiles_and_prob_2(toks[1:], probs, itos)
@@ -366,7 +408,18 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
 
 
 def _plan_for(model, memory):
-    pl = getattr(model, "_last_plan", None)
+    """The plan whose buffers hold `memory`.  Tensors handed out by MultimodalTransformer.forward()/run_model() carry
+    their plan and the serial number of the encoder pass that produced them; a plan that has been re-encoded since
+    (another batch of the same shape) no longer holds this memory, and decoding it would silently use the newer
+    batch, so that is refused.  Tensors without the stamp (clones) fall back to the model's last plan."""
+    stamp = getattr(memory, "_mmst_plan", None)
+    if stamp is not None:
+        pl, serial = stamp
+        if pl.eng is not model._engine or pl.encode_serial != serial:
+            raise L.MMSTError("this memory belongs to an earlier encoder pass: its plan buffers have been reused by a "
+                              "later run_model()/forward() call of the same shape")
+    else:
+        pl = getattr(model, "_last_plan", None)
     if pl is None or memory.shape[1] != pl.B or memory.shape[0] != pl.Lmem:
-        raise L.MMSTError("greedy decode needs the plan of the preceding run_model()/forward() call")
+        raise L.MMSTError("decoding needs the plan of the preceding run_model()/forward() call")
     return pl

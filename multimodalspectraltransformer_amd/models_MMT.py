@@ -112,7 +112,17 @@ class SmilesDecoder(nn.Module):
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):
-        return _engine_of(self).run_decoder(self, tgt, memory, memory_key_padding_mask)
+        if tgt_key_padding_mask is not None or memory_mask is not None:
+            raise L.MMSTError("tgt_key_padding_mask / memory_mask are not supported (the reference never passes them)")
+        causal = True
+        if tgt_mask is None:
+            causal = False
+        else:   # the only mask the reference builds is generate_square_subsequent_mask (models_MMT_v15_4.py:794-800)
+            T = tgt.shape[0]
+            want = torch.triu(torch.full((T, T), float("-inf"), device=tgt_mask.device), diagonal=1)
+            if tuple(tgt_mask.shape) != (T, T) or not torch.equal(tgt_mask.float(), want):
+                raise L.MMSTError("tgt_mask must be None or the causal mask of generate_square_subsequent_mask")
+        return _engine_of(self).run_decoder(self, tgt, memory, memory_key_padding_mask, causal)
 
 
 class _PointEmbedding(nn.Module):
@@ -187,7 +197,7 @@ class _ForwardFn(torch.autograd.Function):
         d = pl.cv.view(pl.dlogits, pl.B, pl.T, VPAD)
         d.zero_()
         d[:, :, :model.out_size] = dlogits.transpose(0, 1)
-        eng.arena.attach_grads(pl.mode)
+        eng.arena.prepare_grads(pl.mode)
         eng.backward(pl, model.training)
         return torch.zeros((), device=dlogits.device), None, None, None
 
@@ -338,6 +348,7 @@ class MultimodalTransformer(nn.Module):
         pl = self.run_encoder_half(batch, T=0 if trg_SMI_input is None else trg_SMI_input.shape[0])
         memory, mask, fingerprint = self.outputs(pl)
         if trg_SMI_input is None:
+            self._last_plan = pl
             return memory, self._embedding_src(pl), mask, fingerprint
         eng = self._engine
         T, B = trg_SMI_input.shape
@@ -347,6 +358,7 @@ class MultimodalTransformer(nn.Module):
         if self.config.use_real_data:
             raise L.MMSTError("use_real_data=True (real_data_linear averaging, :965-971) is not implemented")
         outs = (logits, fingerprint, memory, mask)
+        self._last_plan = pl
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if self._grad_token is None or self._grad_token.device != logits.device:
                 self._grad_token = torch.zeros((), device=logits.device, requires_grad=True)
@@ -368,6 +380,7 @@ class MultimodalTransformer(nn.Module):
         """(memory (L,B,128) fp32, src_padding_mask (B,L), fingerprint (B,512)) of an encoded plan."""
         B, Lm = pl.B, pl.Lmem
         memory = pl.cv.view(pl.memory, B, Lm, D).transpose(0, 1).float()
+        memory._mmst_plan = (pl, pl.encode_serial)   # lets the decode drivers find (and date) the plan behind it
         kb = pl.cv.view(pl.kbias_glob, B, Lm)
         mask = torch.isinf(kb) if pl.mask_is_bool else kb.clone()
         fingerprint = pl.cv.view(pl.fingerprint, B, self.fingerprint_size).clone()
@@ -450,7 +463,7 @@ def _run_encoder(eng, enc, src, key_padding_mask):
     return cur.view(B, S, D).transpose(0, 1).float()
 
 
-def _run_decoder(eng, dec, tgt, memory, memory_key_padding_mask):
+def _run_decoder(eng, dec, tgt, memory, memory_key_padding_mask, causal=True):
     import ctypes as C
     if torch.is_grad_enabled() and dec.training:
         raise L.MMSTError("submodule calls are inference-only; train through MultimodalTransformer.forward")
@@ -462,11 +475,19 @@ def _run_decoder(eng, dec, tgt, memory, memory_key_padding_mask):
     x = tgt.transpose(0, 1).to(bf).contiguous()
     dev = x.device
     # the memory's bf16 batch-first copy and its K/V projections are cached across the steps of a decode loop
+    # (decode loops pass the SAME memory tensor for every token).  The entry holds a reference to that tensor, so its
+    # address cannot be handed to another batch's memory while the entry is alive; a different tensor object, a
+    # modified one, another mask or updated weights all miss.
     cache = eng.__dict__.setdefault("_dec_cache", {})
-    ck = (memory.data_ptr(), tuple(memory.shape), memory._version, T > 1)
-    if cache.get("key", (None,))[:3] != ck[:3]:
+    mk = memory_key_padding_mask
+    hit = (cache.get("memory") is memory and cache.get("version") == memory._version and cache.get("mask") is mk and
+           cache.get("mask_version") == (mk._version if mk is not None else None) and
+           cache.get("weights") is ar and cache.get("weights_version") == ar.weights_serial)
+    if not hit:
         cache.clear()
-        cache["key"] = ck
+        cache.update(memory=memory, version=memory._version, mask=mk,
+                     mask_version=mk._version if mk is not None else None, weights=ar,
+                     weights_version=ar.weights_serial)
         cache["mem"] = memory.transpose(0, 1).to(bf).contiguous()
         mb = additive_mask(memory_key_padding_mask)
         cache["mb"] = mb.contiguous() if mb is not None else None
@@ -497,6 +518,7 @@ def _run_decoder(eng, dec, tgt, memory, memory_key_padding_mask):
             setattr(a, k, buf[k].data_ptr())
         a.kvc = cache["kvc"][l].data_ptr()
         a.kv_ready = int(cache["ready"])
+        a.no_causal = 0 if causal else 1
         a.B, a.T, a.L = B, T, Lm
         L.check(L.lib().mmst_decoder_layer_fwd(C.byref(p), C.byref(a), 16, C.c_float(0.0), C.c_uint32(0),
                                                L.stream_ptr()), "mmst_decoder_layer_fwd")

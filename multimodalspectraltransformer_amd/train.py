@@ -101,6 +101,7 @@ class FusedAdamW:
             ar.M = torch.zeros_like(ar.P)
             ar.V = torch.zeros_like(ar.P)
         self.step_count += 1
+        ar.weights_serial += 1
         st = L.stream_ptr()
         for lo, hi in ar.active_ranges(mode):
             L.check(L.lib().mmst_adamw(C.c_void_p(ar.P.data_ptr() + 4 * lo), C.c_void_p(ar.G.data_ptr() + 4 * lo),
@@ -203,11 +204,11 @@ class TransformerMultiGPU:
             print(f"[reduce] rank {dist.get_rank()} step {batch_idx}: {len(badg)} gradient tensors differ {badg[:3]}, "
                   f"{len(badp)} parameter tensors differ before the update {badp[:3]}", flush=True)
         self.optimizer.step(self.config.training_mode, grad_scale=scale)
-        out = {'loss': loss}
+        out = {'loss': loss.clone()}   # the plan's loss slot is rewritten by the next step
         if getattr(self.config, "gen_SMI_sequence", False):
             from .generate import generate_sequences
             pl = model._last_plan
-            out['gen'] = generate_sequences(model, pl, self.config, self.stoi, self.itos)
+            out['gen'] = generate_sequences(model, pl, self.config, self.stoi, self.itos, temperature=1)
             model.train()
         return out
 
@@ -220,7 +221,17 @@ class TransformerMultiGPU:
             logits, fp, memory, mask = self.forward(x)
             pl = self.model._engine.plan(trg.shape[1], trg.shape[0] - 1, self.config.training_mode)
             loss = self.model._engine.ce_loss(pl, x['trg_enc_SMI'], want_grad=False)
-        return {'loss': loss}
+        return {'loss': loss.clone()}
+
+    def _generate_sequences(self, model, config, memory, src_padding_mask, max_output_len, temperature, stoi, itos):
+        """Reference signature and return tuple (models_MMT_v15_4.py:1222-1297): (gen tensor (max_output_len + 1, B)
+        incl. <SOS>, SMILES list, confidence list) for config.sampling_method greedy / multinomial / mix; like the
+        reference it leaves the model in train mode."""
+        from .generate import _plan_for, generate_sequences
+        pl = _plan_for(model, memory)
+        out = generate_sequences(model, pl, config, stoi, itos, temperature=temperature, max_len=max_output_len)
+        model.train()
+        return out
 
     def on_epoch_end(self, epoch, loss):
         path = os.path.join(self.config.model_save_dir, f"MultimodalTransformer_Epoch_{epoch}_Loss{loss:.3f}.pth")
