@@ -1,8 +1,13 @@
 /* libmmst.so -- C ABI of the MI355X (gfx950) spectral-transformer hot path.
  *
  * Every entry point: plain C, raw DEVICE pointers + sizes + a hipStream_t passed as void*,
- * returns 0 on success or a negative error code (never throws), allocates nothing, keeps no
- * global state, and only ENQUEUES kernels on the given stream (graph-capture safe).
+ * returns 0 on success or a negative error code (never throws), allocates no device memory and
+ * only ENQUEUES kernels on the given stream.  State the library keeps between calls, all of it
+ * listed here: (1) a ring of 64 HIP events per device, created on the first two-stream call
+ * (*_bwd_streams) and reused for the stream hand-offs; (2) the process-wide kernel-path switches
+ * and the diagnostic event tap of mmst_lowlevel.h.  Neither is visible in results.
+ * The building-block launchers underneath (grouped GEMM, attention, fused feed-forward) are
+ * declared in mmst_lowlevel.h.
  *
  * The reference (a PyTorch nn.Module, no FFI of its own) is replaced at the level of the
  * torch.nn calls it makes; each function cites the reference call site it stands in for

@@ -1,43 +1,59 @@
 // Low-level C-ABI: the grouped GEMM and attention launchers, exported for the parity tests
 // and for the one-off projections of the host layer (IR embedding, fingerprint head, vocabulary
 // projection and their gradients).  Structs are plain C (see gemm.h / attn.h).
+#include "../../include/mmst_lowlevel.h"
 #include "attn.h"
 #include "ffn.h"
 #include "gemm.h"
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+// The public structs of include/mmst_lowlevel.h are the kernels' own structs with the bf16 pointer types erased.
+static_assert(sizeof(mmst_gemm_prob) == sizeof(GemmProb) && sizeof(mmst_gemm_batch) == sizeof(GemmBatch), "gemm ABI");
+static_assert(offsetof(mmst_gemm_prob, ldp) == offsetof(GemmProb, ldp) && offsetof(mmst_gemm_prob, seed) == offsetof(GemmProb, seed) &&
+              offsetof(mmst_gemm_prob, ksplit) == offsetof(GemmProb, ksplit) && offsetof(mmst_gemm_prob, qtiles) == offsetof(GemmProb, qtiles) &&
+              offsetof(mmst_gemm_batch, p) == offsetof(GemmBatch, p), "gemm ABI");
+static_assert(sizeof(mmst_attn_prob) == sizeof(AttnProb) && sizeof(mmst_attn_batch) == sizeof(AttnBatch) &&
+              offsetof(mmst_attn_prob, ldq) == offsetof(AttnProb, ldq) && offsetof(mmst_attn_prob, kv_rows) == offsetof(AttnProb, kv_rows) &&
+              offsetof(mmst_attn_batch, p) == offsetof(AttnBatch, p), "attention ABI");
+static_assert(sizeof(mmst_ffn_prob) == sizeof(FfnProb) && sizeof(mmst_ffn_batch) == sizeof(FfnBatch) &&
+              offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit), "ffn ABI");
+static_assert(sizeof(mmst_ffn_wgrad_prob) == sizeof(FfnWgradProb) && sizeof(mmst_ffn_wgrad_batch) == sizeof(FfnWgradBatch) &&
+              offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M), "ffn weight-gradient ABI");
+static_assert(MMST_GEMM_MAX_GROUPS == GEMM_MAX_GROUPS && MMST_EPI_ATOMIC == EPI_ATOMIC && MMST_GF_OUT_F32 == GF_OUT_F32, "gemm ABI");
+
 extern "C" {
 
-int mmst_gemm(const GemmBatch* batch, int epi, int p_contraction_major, int q_contraction_major, void* stream) {
+int mmst_gemm(const mmst_gemm_batch* batch, int epi, int p_contraction_major, int q_contraction_major, void* stream) {
   if (!batch) return MMST_ERR_ARG;
-  GemmBatch b = *batch;
+  GemmBatch b = *reinterpret_cast<const GemmBatch*>(batch);
   return launch_gemm(b, epi, p_contraction_major != 0, q_contraction_major != 0, (hipStream_t)stream);
 }
 
-int mmst_attn_fwd(const AttnBatch* batch, void* stream) {
+int mmst_attn_fwd(const mmst_attn_batch* batch, void* stream) {
   if (!batch) return MMST_ERR_ARG;
-  AttnBatch b = *batch;
+  AttnBatch b = *reinterpret_cast<const AttnBatch*>(batch);
   return launch_attn_fwd(b, (hipStream_t)stream);
 }
 
-int mmst_attn_bwd(const AttnBatch* batch, void* stream) {
+int mmst_attn_bwd(const mmst_attn_batch* batch, void* stream) {
   if (!batch) return MMST_ERR_ARG;
-  AttnBatch b = *batch;
+  AttnBatch b = *reinterpret_cast<const AttnBatch*>(batch);
   return launch_attn_bwd(b, (hipStream_t)stream);
 }
 
 // fused feed-forward block: backward == 0 -> y = LN(x + drop(FFN(x))), else the activation-gradient pass
-int mmst_ffn(const FfnBatch* batch, int backward, void* stream) {
+int mmst_ffn(const mmst_ffn_batch* batch, int backward, void* stream) {
   if (!batch) return MMST_ERR_ARG;
-  FfnBatch b = *batch;
+  FfnBatch b = *reinterpret_cast<const FfnBatch*>(batch);
   return backward ? launch_ffn_bwd(b, (hipStream_t)stream) : launch_ffn_fwd(b, (hipStream_t)stream);
 }
 
 // feed-forward weight gradients with the hidden gradient recomputed in the kernel (accumulating)
-int mmst_ffn_wgrad(const FfnWgradBatch* batch, void* stream) {
+int mmst_ffn_wgrad(const mmst_ffn_wgrad_batch* batch, void* stream) {
   if (!batch) return MMST_ERR_ARG;
-  FfnWgradBatch b = *batch;
+  FfnWgradBatch b = *reinterpret_cast<const FfnWgradBatch*>(batch);
   return launch_ffn_wgrad(b, (hipStream_t)stream);
 }
 
@@ -71,7 +87,7 @@ int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, i
   return MMST_OK;
 }
 
-int mmst_tap_reset() {
+int mmst_tap_reset(void) {
   g_gemm_tap.count = 0; g_gemm_tap.flops = 0.0; g_gemm_tap.bytes = 0.0;
   return MMST_OK;
 }
@@ -94,9 +110,9 @@ int mmst_tap_read(float* total_ms, int* count, double* flops, double* bytes, cha
   return MMST_OK;
 }
 
-int mmst_sizeof_gemm_batch() { return (int)sizeof(GemmBatch); }
-int mmst_sizeof_attn_batch() { return (int)sizeof(AttnBatch); }
-int mmst_sizeof_ffn_batch() { return (int)sizeof(FfnBatch); }
-int mmst_sizeof_ffn_wgrad_batch() { return (int)sizeof(FfnWgradBatch); }
-int mmst_version() { return 1; }
+int mmst_sizeof_gemm_batch(void) { return (int)sizeof(GemmBatch); }
+int mmst_sizeof_attn_batch(void) { return (int)sizeof(AttnBatch); }
+int mmst_sizeof_ffn_batch(void) { return (int)sizeof(FfnBatch); }
+int mmst_sizeof_ffn_wgrad_batch(void) { return (int)sizeof(FfnWgradBatch); }
+int mmst_version(void) { return 2; }
 }

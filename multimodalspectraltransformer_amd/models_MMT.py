@@ -354,7 +354,9 @@ class MultimodalTransformer(nn.Module):
         T, B = trg_SMI_input.shape
         pl.cv.view(pl.tok, self.max_len + 1, B)[:T].copy_(trg_SMI_input)
         eng.decode(pl, self.training, T=T)
-        logits = pl.cv.view(pl.logits, B, T, VPAD)[:, :, :self.out_size].transpose(0, 1)
+        # a tensor of its own, (T, B, V) contiguous like the reference's: the plan's logits buffer is rewritten by the
+        # next call of the same shape
+        logits = pl.cv.view(pl.logits, B, T, VPAD)[:, :, :self.out_size].transpose(0, 1).contiguous()
         if self.config.use_real_data:
             raise L.MMSTError("use_real_data=True (real_data_linear averaging, :965-971) is not implemented")
         outs = (logits, fingerprint, memory, mask)

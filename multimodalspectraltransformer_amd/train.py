@@ -8,6 +8,7 @@ layers are still in backward.
 import ctypes as C
 import json
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -157,6 +158,10 @@ class TransformerMultiGPU:
         self.scheduler = None
         self.reducer = None
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.start_time = time.time()
+        self.current_epoch = 0
+        self.global_step = 0
+        self.last_train_loss = None    # device tensor of the latest training_step (read only when a file is written)
 
     def to(self, device):
         self.model.to(device)
@@ -205,6 +210,8 @@ class TransformerMultiGPU:
                   f"{len(badp)} parameter tensors differ before the update {badp[:3]}", flush=True)
         self.optimizer.step(self.config.training_mode, grad_scale=scale)
         out = {'loss': loss.clone()}   # the plan's loss slot is rewritten by the next step
+        self.last_train_loss = out['loss']
+        self.global_step += 1
         if getattr(self.config, "gen_SMI_sequence", False):
             from .generate import generate_sequences
             pl = model._last_plan
@@ -234,20 +241,94 @@ class TransformerMultiGPU:
         return out
 
     def on_epoch_end(self, epoch, loss):
+        """Per-epoch weights file, models_MMT_v15_4.py:1190-1194."""
         path = os.path.join(self.config.model_save_dir, f"MultimodalTransformer_Epoch_{epoch}_Loss{loss:.3f}.pth")
         torch.save(self.model.state_dict(), path)
         return path
 
+    def on_batch_end(self):
+        """Wall-clock checkpoints, models_MMT_v15_4.py:1196-1210: once config.model_save_interval seconds have passed
+        since the last one, write the weights (.pth) and a Lightning-layout checkpoint (.ckpt) and restart the clock.
+        Returns the two paths, or None when nothing was due."""
+        interval = getattr(self.config, "model_save_interval", None)
+        if interval is None or time.time() - self.start_time < interval:
+            return None
+        loss = float(self.last_train_loss) if self.last_train_loss is not None else float("nan")
+        base = os.path.join(self.config.model_save_dir, f"MultimodalTransformer_time_{str(time.time())}_Loss_{loss:.3f}")
+        torch.save(self.model.state_dict(), base + ".pth")
+        self.save_checkpoint(base + ".ckpt")
+        self.start_time = time.time()
+        return base + ".pth", base + ".ckpt"
+
+    def state_dict(self):
+        """Keys of the reference LightningModule's state_dict: the model's, prefixed 'model.'."""
+        return {"model." + k: v for k, v in self.model.state_dict().items()}
+
+    def save_checkpoint(self, path):
+        """A file in the layout of pytorch_lightning's Trainer.save_checkpoint as the reference's loaders use it
+        (mmt_result_test_functions_15_4.py:467-475, MT_functions_v15_4.py:121-123): a dict whose 'state_dict' maps
+        'model.<key>' to tensors, with the training position and the optimizer state beside it.  Only tensors and
+        plain Python values are stored, so the file loads with torch.load(weights_only=True)."""
+        ckpt = {"epoch": int(self.current_epoch), "global_step": int(self.global_step),
+                "pytorch-lightning_version": "0.7.3",
+                "state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()}}
+        opt = self.optimizer
+        if opt is not None:
+            ar = self.model._engine.arena
+            state = {"lr": float(opt.lr), "betas": [float(b) for b in opt.betas], "eps": float(opt.eps),
+                     "weight_decay": float(opt.wd), "step": int(opt.step_count)}
+            if ar is not None and ar.M is not None:
+                state["exp_avg"] = {k: ar.M[ar.offset[k]: ar.offset[k] + ar.numel[k]].view(ar.named[k].shape).cpu().clone()
+                                    for k in ar.order}
+                state["exp_avg_sq"] = {k: ar.V[ar.offset[k]: ar.offset[k] + ar.numel[k]].view(ar.named[k].shape).cpu().clone()
+                                       for k in ar.order}
+            ckpt["optimizer_states"] = [state]
+            if self.scheduler is not None:
+                ckpt["lr_schedulers"] = [{"best": float(self.scheduler.best), "num_bad_epochs": int(self.scheduler.bad),
+                                          "factor": float(self.scheduler.factor), "patience": int(self.scheduler.patience)}]
+        torch.save(ckpt, path)
+        return path
+
     @classmethod
-    def load_from_checkpoint(cls, checkpoint_path, config=None):
+    def load_from_checkpoint(cls, checkpoint_path, config=None, resume_optimizer=False):
         """Reads the reference's .ckpt (Lightning dict, keys prefixed 'model.') or .pth (plain state_dict)
-        with a loader that executes nothing from the file."""
+        with a loader that executes nothing from the file.  resume_optimizer=True also restores the AdamW moments,
+        step count, learning rate and plateau scheduler of a checkpoint written by save_checkpoint()."""
         self = cls(config)
         sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        if "state_dict" in sd:
-            sd = {k[len("model."):]: v for k, v in sd["state_dict"].items() if k.startswith("model.")}
+        full = sd if "state_dict" in sd else None
+        if full is not None:
+            sd = {k[len("model."):]: v for k, v in full["state_dict"].items() if k.startswith("model.")}
         self.model.load_state_dict(sd)
+        if full is not None:
+            self.current_epoch = int(full.get("epoch", 0))
+            self.global_step = int(full.get("global_step", 0))
+            if resume_optimizer and full.get("optimizer_states"):
+                self._resume_state = (full["optimizer_states"][0], (full.get("lr_schedulers") or [None])[0])
         return self
+
+    def restore_optimizer(self):
+        """Second half of load_from_checkpoint(resume_optimizer=True): call once the model sits on its device."""
+        st = getattr(self, "_resume_state", None)
+        if st is None:
+            return False
+        ost, sst = st
+        if self.optimizer is None:
+            self.configure_optimizers()
+        opt, eng = self.optimizer, self.model._engine
+        eng.ensure(self.model._dev())
+        ar = eng.arena
+        opt.lr, opt.betas, opt.eps, opt.wd = ost["lr"], tuple(ost["betas"]), ost["eps"], ost["weight_decay"]
+        opt.step_count = int(ost["step"])
+        if "exp_avg" in ost:
+            ar.M, ar.V = torch.zeros_like(ar.P), torch.zeros_like(ar.P)
+            for k in ar.order:
+                ar.M[ar.offset[k]: ar.offset[k] + ar.numel[k]].copy_(ost["exp_avg"][k].reshape(-1))
+                ar.V[ar.offset[k]: ar.offset[k] + ar.numel[k]].copy_(ost["exp_avg_sq"][k].reshape(-1))
+        if sst is not None:
+            self.scheduler.best, self.scheduler.bad = sst["best"], sst["num_bad_epochs"]
+        self._resume_state = None
+        return True
 
 
 def run_training_MMT(config, batches, num_epochs=None, log=print):
@@ -257,9 +338,12 @@ def run_training_MMT(config, batches, num_epochs=None, log=print):
     tm.to(config.device)
     tm.configure_optimizers()
     for epoch in range(num_epochs or config.num_epochs):
+        tm.current_epoch = epoch
         losses = []
         for i, batch in enumerate(batches(epoch)):
             losses.append(tm.training_step(batch, i)['loss'])
+            if config.save_model and (not dist.is_initialized() or dist.get_rank() == 0):
+                tm.on_batch_end()
         mean = float(torch.stack(losses).mean()) if losses else float("nan")
         if dist.is_initialized():
             t = torch.tensor([mean], device=config.device)

@@ -234,11 +234,26 @@ def greedy_case(M, vg, name, mode, nl, B, seed, wseed, want_margin=2.0):
     assert torch.equal(toks, want), "fitted model does not decode its targets"
     assert toks.shape[0] < cfg.max_len and bool((toks[-1] == 0).all()), "stop rule (all <PAD>) did not fire"
     trained = {'trained/' + k: np_(sd[k]) for k in trained_keys(nl)}
+    # in-training generation of the LightningModule wrapper (models_MMT_v15_4.py:1222-1297): no early stop, a given
+    # number of steps (62 = the positions the readout was fitted on), greedy; plus the distribution of position 0
+    # given <SOS>, which is all that its "multinomial" mode ever samples from
+    GEN_LEN = 62
+    cfg.sampling_method = "greedy"
+    gen_t, gen_smi, gen_conf = M.TransformerMultiGPU._generate_sequences(None, model, cfg, memory, mask, GEN_LEN, 1,
+                                                                       stoi, itos)
+    model.eval()
+    _, _, gmargins = O.greedy_sequence(sd, ocfg, memory, mask, early_stop=False, max_len=GEN_LEN)
+    assert float(gmargins.min()) > want_margin
+    with torch.no_grad():
+        p0 = torch.softmax(O.decode_logits(sd, ocfg, torch.full((1, B), stoi["<SOS>"], dtype=torch.long), memory, mask)[-1], dim=1)
+    gen = {'gen/tokens': np_(gen_t), 'gen/smiles': np.array(gen_smi), 'gen/len': np.int64(GEN_LEN),
+           'gen/conf_len': np.array([len(c) for c in gen_conf], np.int64),
+           'gen/conf0': np.array([float(c[0]) for c in gen_conf], np.float64), 'gen/p0': np_(p0)}
     np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'),
                         tokens=np_(toks), probs=np_(probs), memory=digest(memory, 512), mask=np_(mask.float()),
                         fingerprint=np_(fp), margins=np_(margins), smiles=np.array(smiles),
                         seed=np.int64(seed), wseed=np.int64(wseed), B=np.int64(B), nl=np.int64(nl),
-                        gain=np.float64(1.0), **trained)
+                        gain=np.float64(1.0), **trained, **gen)
     print(name, 'steps', toks.shape, 'min margin', float(margins.min()), smiles[:2])
 
 
@@ -440,6 +455,18 @@ def data_case(dl):
     print('data ok', out['formulas'][:3], out['mw'][:3])
 
 
+def ckpt_case(M):
+    """state_dict keys of the reference's LightningModule wrapper (what its .ckpt files hold under 'state_dict') and
+    of the bare model (its .pth files), for a one-layer configuration."""
+    cfg = ref_config(training_mode='1H_HSQC_COSY_IR_MF_MW', num_encoder_layers=1, num_decoder_layers=1)
+    tm = M.TransformerMultiGPU(cfg)
+    keys = list(tm.state_dict().keys())
+    shapes = {k: list(v.shape) for k, v in tm.state_dict().items()}
+    json.dump(dict(wrapper_keys=keys, model_keys=list(tm.model.state_dict().keys()), shapes=shapes),
+              open(os.path.join(ROOT, 'tests', 'golden', 'ckpt_keys.json'), 'w'))
+    print('ckpt keys', len(keys), keys[:2])
+
+
 def full_case(M):
     """The benchmark configuration at its real size (64 molecules, 6 + 6 layers): loss, logits digest, a digest of
     every parameter gradient and one AdamW step of the reference."""
@@ -462,6 +489,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'clip':      # only the CLIP-head fixture
         clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'ckpt':      # only the checkpoint key lists
+        ckpt_case(M)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'full':      # only the full-size fixture of the benchmark configuration
         full_case(M)
         return
@@ -477,6 +507,7 @@ def main():
     forward_case(M, 'fwd_ms_L1', '1H_13C_HSQC_COSY_IR_MF_MS_MW', 1, 2, seed=14, wseed=104)
     forward_case(M, 'fwd_nomf_L1', '1H_HSQC_COSY_IR', 1, 2, seed=15, wseed=105)
     forward_case(M, 'fwd_c2_L6', '1H_HSQC_COSY_IR_MF_MW', 6, 2, seed=16, wseed=106, with_grads=False)
+    ckpt_case(M)
     full_case(M)
     greedy_cases(M, vg)
     beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)

@@ -21,15 +21,29 @@ PKG = os.path.join(ROOT, "multimodalspectraltransformer_amd")
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "mmst.h")).read()
-    names = sorted(set(re.findall(r"^\s*int\s+(mmst_\w+)\s*\(", hdr, flags=re.M)))
-    assert len(names) >= 14
-    lib = ctypes.CDLL(os.path.join(PKG, "libmmst.so"))
-    for n in names:
+    """Every entry point declared in include/*.h is exported by libmmst.so, and the library exports nothing that
+    the headers do not declare."""
+    declared = set()
+    for h in ("mmst.h", "mmst_lowlevel.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        declared |= set(re.findall(r"^\s*int\s+(mmst_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 48
+    so = os.path.join(PKG, "libmmst.so")
+    lib = ctypes.CDLL(so)
+    for n in sorted(declared):
         assert hasattr(lib, n), f"libmmst.so does not export {n}"
-    for n in ("mmst_gemm", "mmst_attn_fwd", "mmst_attn_bwd", "mmst_tap_config", "mmst_tap_read"):
-        assert hasattr(lib, n)
-    assert lib.mmst_version() >= 1
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\sT\s+(mmst_\w+)", out))
+    assert exported - declared == set(), f"exported but not declared in include/: {sorted(exported - declared)}"
+    assert lib.mmst_version() >= 2
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """`--gpus N` must never silently measure another number of ranks."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode != 0 and "--gpus 4" in out.stderr and "{" not in out.stdout
 
 
 def test_ctypes_structs_match_library():

@@ -1,0 +1,210 @@
+"""The LightningModule-shaped wrapper and the torch-facing module surface on the GPU: in-training generation
+(TransformerMultiGPU._generate_sequences), validation_step, a plain torch optimizer around the autograd path,
+and the guards of the decode drivers.  Fixtures come from the reference (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmt_oracle as O
+from tests.test_model_gpu import GREEDY, build, call, make_config
+from tests.util import GOLDEN, digest, digest_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multimodalspectraltransformer_amd import _lib as L
+    from multimodalspectraltransformer_amd import generate as gen
+    from multimodalspectraltransformer_amd.train import TransformerMultiGPU, run_training_MMT
+
+MODE = "1H_HSQC_COSY_IR_MF_MW"
+
+
+def _wrapper_on(g, mode):
+    model, config, cfg, sd, batch, db = build(g, mode, gain=float(g["gain"]))
+    tm = TransformerMultiGPU.__new__(TransformerMultiGPU)   # the fitted model of the fixture, not fresh weights
+    tm.config, tm.model = config, model
+    stoi = json.load(open(os.path.join(GOLDEN, "stoi.json")))
+    itos = json.load(open(os.path.join(GOLDEN, "itos.json")))
+    db["src_HSQC_"], db["src_COSY_"] = db["src_HSQC"], db["src_COSY"]
+    memory, mask, trg, fp, _, _ = gen.run_model(model, db, config)
+    return tm, model, config, memory, mask, stoi, itos
+
+
+@pytest.mark.parametrize("name,mode", GREEDY[:2])
+def test_generate_sequences_greedy_vs_reference(name, mode):
+    """_generate_sequences(model, config, memory, mask, max_len, temperature, stoi, itos), sampling_method greedy:
+    the reference's token tensor (incl. <SOS>, no early stop), SMILES strings and confidence lengths, identical."""
+    g = load_golden(name)
+    tm, model, config, memory, mask, stoi, itos = _wrapper_on(g, mode)
+    config.sampling_method = "greedy"
+    n = int(g["gen/len"])
+    toks, smiles, conf = tm._generate_sequences(model, config, memory, mask, n, 1, stoi, itos)
+    assert model.training   # the reference leaves the model in train mode (:1268)
+    assert np.array_equal(toks.cpu().numpy(), g["gen/tokens"])
+    assert smiles == [str(s_) for s_ in g["gen/smiles"]]
+    assert [len(c) for c in conf] == g["gen/conf_len"].tolist()
+    np.testing.assert_allclose([float(c[0]) for c in conf], g["gen/conf0"], atol=2e-2)
+
+
+def test_generate_sequences_multinomial_and_mix():
+    """The two sampling quirks of the reference (models_MMT_v15_4.py:1241, :1258-1264, :1294): "multinomial" samples
+    every step from the distribution of position 0 given <SOS> (the decoder input never grows); "mix" returns the
+    greedy tokens with the multinomial confidences cut to the greedy strings' lengths."""
+    name, mode = GREEDY[0]
+    g = load_golden(name)
+    tm, model, config, memory, mask, stoi, itos = _wrapper_on(g, mode)
+    n, B = int(g["gen/len"]), int(g["B"])
+    p0 = g["gen/p0"]
+    config.sampling_method = "multinomial"
+    torch.manual_seed(5)
+    toks, smiles, conf = tm._generate_sequences(model, config, memory, mask, 128, 1, stoi, itos)
+    toks = toks.cpu().numpy()
+    assert toks.shape == (129, B) and (toks[0] == stoi["<SOS>"]).all() and len(smiles) == B
+    counts = np.stack([np.bincount(toks[1:, b], minlength=p0.shape[1]) for b in range(B)]) / 128.0
+    # 128 draws per molecule from p0: frequencies within 4.5 standard deviations of a binomial proportion
+    sigma = np.sqrt(p0 * (1 - p0) / 128.0)
+    assert (np.abs(counts - p0) <= 4.5 * sigma + 2e-2).all()
+    assert not np.array_equal(toks[1:n + 1], g["gen/tokens"][1:])   # not the greedy continuation
+    # the confidences are p0[token]: the position-0 distribution, whatever was sampled before
+    for b in range(B):
+        c = conf[b].cpu().numpy()
+        np.testing.assert_allclose(c, p0[b, toks[1:1 + len(c), b]], atol=2e-2)
+    config.sampling_method = "mix"
+    toks2, smiles2, conf2 = tm._generate_sequences(model, config, memory, mask, n, 1, stoi, itos)
+    assert np.array_equal(toks2.cpu().numpy(), g["gen/tokens"])
+    assert smiles2 == [str(s_) for s_ in g["gen/smiles"]]
+    assert [len(c) for c in conf2] == g["gen/conf_len"].tolist()
+    assert all(float(c.min()) > 0 and float(c.max()) <= 1 for c in conf2 if len(c))
+    # the fitted model is confident: a token sampled from the greedy-prefix distribution is nearly always the greedy
+    # one, so the multinomial confidences are close to the greedy ones
+    assert np.median([float(c.mean()) for c in conf2 if len(c)]) > 0.8
+
+
+def test_validation_step_loss_vs_reference():
+    g = load_golden("fwd_c2_L2")
+    model, config, cfg, sd, batch, db = build(g, MODE)
+    tm = TransformerMultiGPU.__new__(TransformerMultiGPU)
+    tm.config, tm.model = config, model
+    out = tm.validation_step(dict(db), 0)
+    assert not model.training
+    assert abs(float(out["loss"]) - float(g["loss"])) < 5e-3
+    # the returned loss is a value of its own, not a view of the slot the next step overwrites
+    keep = float(out["loss"])
+    other = {k: v.flip(0) if k == "trg_enc_SMI" else v for k, v in db.items()}
+    out2 = tm.validation_step(other, 1)
+    assert float(out["loss"]) == keep and float(out2["loss"]) != keep
+    assert out["loss"].data_ptr() != out2["loss"].data_ptr()
+
+
+def test_torch_optimizer_around_autograd_path_vs_reference():
+    """`zero_grad(); model(...); loss.backward(); optimizer.step()` with torch.optim.AdamW and its default
+    zero_grad(set_to_none=True), two steps: step losses and post-step weights of the reference's own two AdamW steps
+    (gradients must not pile up in the flat buffer), then eval-mode forward sees the updated weights."""
+    g = load_golden("fwd_c2_L2")
+    model, config, cfg, sd, batch, db = build(g, MODE)
+    model.eval()   # the fixture was taken in eval mode (dropout off), gradients enabled
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg["lr_pretraining"])
+    trg = db["trg_enc_SMI"].t()
+    losses = []
+    for step in range(2):
+        opt.zero_grad()
+        logits, fp, memory, mask = call(model, MODE, db, trg[:-1, :])
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), trg[1:, :].reshape(-1))
+        loss.backward()
+        if step == 1:   # second-step gradients against the oracle at the current weights
+            cur = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+            O.training_forward(cur, cfg, batch)[0].backward()
+            for k in ("decoder.layers.1.linear1.weight", "encoder_cross.layers.0.self_attn.in_proj_weight",
+                      "encoder_HSQC.layers.1.linear2.weight", "fc_out.weight", "embed_trg.weight"):
+                a = dict(model.named_parameters())[k].grad.detach().cpu().reshape(-1).double()
+                b = cur[k].grad.reshape(-1).double()
+                assert float(a @ b / (a.norm() * b.norm())) > 0.99 and abs(float(a.norm() / b.norm()) - 1) < 0.1, k
+        opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g["step_losses"], atol=6e-3)
+    post = model.state_dict()
+    for k in g.files:
+        if k.startswith("post/"):
+            digest_close(digest(post[k[5:]]), g[k], 2e-4, 2e-4)
+    # eval-mode inference after an external optimizer step runs on the updated weights
+    with torch.no_grad():
+        l2 = call(model, MODE, db, trg[:-1, :])[0]
+        want = O.training_forward({k: v.cpu() for k, v in post.items()}, cfg, batch)[1]
+    assert float((l2.cpu() - want).abs().max()) < 4e-2
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+        l3 = call(model, MODE, db, trg[:-1, :])[0]
+    assert float((l3 - l2).abs().max()) > 1e-3
+
+
+def test_epoch_mean_is_the_mean_of_the_step_losses(tmp_path):
+    """run_training_MMT reports (and schedules the learning rate on) the mean of the epoch's step losses; the losses
+    training_step returns are values of their own, not views of a slot that later steps overwrite."""
+    config, cfg = make_config(MODE, 1, drop_out=0.0, model_save_dir=str(tmp_path), num_epochs=1)
+    batches = [{k: v.cuda() for k, v in O.synthetic_batch(4, 60 + i, MODE).items()} for i in range(3)]
+    torch.manual_seed(11)
+    tm = TransformerMultiGPU(config).to("cuda")
+    tm.configure_optimizers()
+    kept = [tm.training_step(b, i)["loss"] for i, b in enumerate(batches)]
+    vals = [float(x) for x in kept]
+    assert len(set(round(v, 4) for v in vals)) == 3      # three different batches, three different losses
+    logged = []
+    torch.manual_seed(11)                                 # same initial weights, same batches, same dropout seeds
+    run_training_MMT(config, lambda epoch: batches, num_epochs=1, log=logged.append)
+    mean = float(logged[-1].split("loss")[1].split()[0])
+    assert abs(mean - float(np.mean(vals))) < 5e-3, (mean, vals)
+    assert abs(mean - vals[-1]) > 1e-3                    # in particular not the last step's loss
+
+
+def test_decode_refuses_a_stale_memory():
+    g = load_golden("fwd_c2_L2")
+    model, config, cfg, sd, batch, db = build(g, MODE)
+    stoi = json.load(open(os.path.join(GOLDEN, "stoi.json")))
+    db["src_HSQC_"], db["src_COSY_"] = db["src_HSQC"], db["src_COSY"]
+    mem_a, mask_a, *_ = gen.run_model(model, db, config)
+    other = {k: v.flip(0) for k, v in db.items()}
+    mem_b, mask_b, *_ = gen.run_model(model, other, config)
+    short = type(config)(**dict(vars(config), max_len=6))
+    with pytest.raises(L.MMSTError):
+        gen.greedy_sequence(model, stoi, None, mem_a, mask_a, short)
+    toks, _ = gen.greedy_sequence(model, stoi, None, mem_b, mask_b, short)
+    assert toks.shape[1] == int(g["B"])
+    # memory returned by forward() is decodable as well (forward registers its plan)
+    model.eval()
+    with torch.no_grad():
+        mem_c, _, mask_c, _ = call(model, MODE, db, None)
+    toks_c, _ = gen.greedy_sequence(model, stoi, None, mem_c, mask_c, short)
+    assert toks_c.shape == toks.shape
+
+
+def test_decoder_submodule_mask_handling_and_cache():
+    """model.decoder(...): tgt_mask=None means no causal mask (last row of a one-layer decoder is unchanged, earlier
+    rows are not), an arbitrary mask is refused, and the cached memory projections never serve another memory."""
+    g = load_golden("fwd_all_L1")
+    model, config, cfg, sd, batch, db = build(g, "1H_13C_HSQC_COSY_IR_MF_MW")
+    model.eval()
+    gen_ = torch.Generator().manual_seed(2)
+    mem = torch.randn(40, 3, 128, generator=gen_).cuda()
+    tgt = torch.randn(9, 3, 128, generator=gen_).cuda()
+    with torch.no_grad():
+        causal = model.decoder(tgt, mem, tgt_mask=model.generate_square_subsequent_mask(9))
+        full = model.decoder(tgt, mem, tgt_mask=None)
+        assert float((causal[-1] - full[-1]).abs().max()) < 1e-2
+        assert float((causal[0] - full[0]).abs().max()) > 5e-2
+        want = O.decoder(tgt.cpu(), mem.cpu(), sd, 1, 16, None)
+        assert float((causal.cpu() - want).abs().max()) < 6e-2
+        with pytest.raises(L.MMSTError):
+            model.decoder(tgt, mem, tgt_mask=torch.zeros(9, 9).cuda())
+        # same shape, new values written IN PLACE into the same tensor: the cached K/V projections must not be reused
+        mem.copy_(torch.randn(40, 3, 128, generator=gen_))
+        again = model.decoder(tgt, mem, tgt_mask=model.generate_square_subsequent_mask(9))
+        want2 = O.decoder(tgt.cpu(), mem.cpu(), sd, 1, 16, None)
+        assert float((again.cpu() - want2).abs().max()) < 6e-2
+        # and a different tensor object of the same shape
+        mem3 = torch.randn(40, 3, 128, generator=gen_).cuda()
+        third = model.decoder(tgt, mem3, tgt_mask=model.generate_square_subsequent_mask(9))
+        assert float((third.cpu() - O.decoder(tgt.cpu(), mem3.cpu(), sd, 1, 16, None)).abs().max()) < 6e-2
