@@ -5,7 +5,8 @@
  * only ENQUEUES kernels on the given stream.  State the library keeps between calls, all of it
  * listed here: (1) a ring of 64 HIP events per device, created on the first two-stream call
  * (*_bwd_streams) and reused for the stream hand-offs; (2) the process-wide kernel-path switches
- * and the diagnostic event tap of mmst_lowlevel.h.  Neither is visible in results.
+ * and the diagnostic event tap of mmst_lowlevel.h; (3) the per-device static scratch array of the
+ * one *_static entry point.  None of the three is visible in results.
  * The building-block launchers underneath (grouped GEMM, attention, fused feed-forward) are
  * declared in mmst_lowlevel.h.
  *
@@ -149,6 +150,18 @@ typedef struct {
   int B, pos, cap, L;
 } mmst_dec_step;
 int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, int nhead, void* stream);
+
+/* The same token step for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): mmst_decoder_layer_step with its scratch rows (attn, x1, qc, x2, h, lse,
+ * ffn_ws of mmst_dec_step) taken from a static device array inside the library instead of from the caller.  It has NO
+ * counterpart in the reference; it exists for those callers only.  The caller still passes the input row, the output
+ * row and the caches.  Limits: B <= MMST_STATIC_STEP_MAX_B (larger B returns -1, nothing is launched); the array
+ * (about 2.3 MB) exists once per GPU for the life of the process and is shared by every call on that GPU, so two calls
+ * that overlap on one GPU (different streams or threads) race -- serialise them.  The call itself allocates nothing
+ * and frees nothing; its results equal mmst_decoder_layer_step's bit for bit. */
+#define MMST_STATIC_STEP_MAX_B 256
+int mmst_decoder_layer_step_static(const mmst_dec_params* p, const void* x, void* y, void* qkv_cache, const void* kvc,
+                                   const float* mem_bias, int B, int pos, int cap, int L, int nhead, void* stream);
 
 /* ---- one new target position through ALL decoder layers in one launch (inference) ----
  * Same inputs, caches and arithmetic as n_layers calls of mmst_decoder_layer_step (one workgroup per sequence walks

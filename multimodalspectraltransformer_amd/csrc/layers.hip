@@ -541,6 +541,65 @@ int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, in
 
 }  // extern "C"
 
+// ---- the token step for callers that cannot allocate: the scratch rows live in a static device array ----
+namespace {
+
+constexpr int STATIC_MAX_B = MMST_STATIC_STEP_MAX_B;
+// carve-up of the array, every part a multiple of 256 bytes
+constexpr size_t SC_ROW = (size_t)STATIC_MAX_B * D * sizeof(bf16);           // attn, x1, qc, x2: [B][128] bf16 each
+constexpr size_t SC_H = (size_t)STATIC_MAX_B * FF * sizeof(bf16);            // h: [B][2048] bf16
+constexpr size_t SC_LSE = (size_t)STATIC_MAX_B * 16 * sizeof(float);         // lse: [B][16] fp32
+constexpr size_t SC_WS = (size_t)FFN_MAX_HSPLIT * STATIC_MAX_B * D * sizeof(float);   // ffn_ws: [8][B][128] fp32
+constexpr size_t SC_TOTAL = 4 * SC_ROW + SC_H + SC_LSE + SC_WS;
+static_assert(SC_ROW % 256 == 0 && SC_H % 256 == 0 && SC_LSE % 256 == 0 && SC_WS % 256 == 0, "scratch alignment");
+
+}  // namespace
+
+// One copy per GPU, held until the process ends.  The name below is a host-side stand-in: device code and kernel
+// arguments use the address hipGetSymbolAddress returns for the current device (scratch_base()).
+static __device__ __align__(256) unsigned char scratch[SC_TOTAL];
+
+namespace {
+
+unsigned char* scratch_base() {
+  constexpr int MAX_DEV = 16;
+  static unsigned char* base[MAX_DEV];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!base[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return nullptr;
+    base[dev] = (unsigned char*)ptr;
+  }
+  return base[dev];
+}
+
+}  // namespace
+
+extern "C" int mmst_decoder_layer_step_static(const mmst_dec_params* p, const void* x, void* y, void* qkv_cache,
+                                              const void* kvc, const float* mem_bias, int B, int pos, int cap, int L,
+                                              int nhead, void* stream_) {
+  if (B < 1 || B > STATIC_MAX_B) return MMST_ERR_ARG;   // the array holds the scratch rows of at most 256 sequences
+  unsigned char* base = scratch_base();
+  if (!base) return MMST_ERR_LAUNCH;
+  mmst_dec_step s;
+  memset(&s, 0, sizeof(s));
+  s.x = x; s.y = y; s.qkv_cache = qkv_cache; s.kvc = kvc; s.mem_bias = mem_bias;
+  s.attn = base;
+  s.x1 = base + SC_ROW;
+  s.qc = base + 2 * SC_ROW;
+  s.x2 = base + 3 * SC_ROW;
+  s.h = base + 4 * SC_ROW;
+  s.lse = (float*)(base + 4 * SC_ROW + SC_H);
+  s.ffn_ws = (float*)(base + 4 * SC_ROW + SC_H + SC_LSE);
+  s.B = B; s.pos = pos; s.cap = cap; s.L = L;
+  // every scratch row a call reads it has written before (projections, attention rows, hidden tiles and the
+  // partial-sum slabs of the split feed-forward block), so nothing needs clearing between calls
+  return mmst_decoder_layer_step(p, &s, nhead, stream_);
+}
+
 namespace {
 
 // Decoder layer backward, activation gradients.  wst == nullptr: everything on st.  Otherwise the part of the
