@@ -273,6 +273,17 @@ int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* 
 int mmst_ce_loss(const float* logits, int ldl, int V, const int64_t* trg, int trg_ld, int B, int T, float* loss,
                  void* dlogits, float grad_scale, void* stream);
 
+/* config.use_real_data branch of MultimodalTransformer.forward (:965-971): logits <- (logits + extra[b]) / 2 with
+ * extra = real_data_linear(mean(memory)) [B][64] fp32 (a GEMM on the 64-row padded weight); logits fp32 [B*T][64]. */
+int mmst_real_data_mix(float* logits, const float* extra, int B, int T, void* stream);
+/* Row part of its backward: d_extra[b][c] = sum_t dlogits[b][t][c] (dlogits bf16 [B*T][64], already scaled by 1/2
+ * through mmst_ce_loss's grad_scale), dbias[c] += sum_b d_extra[b][c], mean32 = fp32 copy of mean [B][128].  The
+ * weight gradient and d_mean are mmst_sgemm products of d_extra; d_mean reaches the memory through
+ * mmst_seq_mean_bwd_add: dmem[b][l][:] += dmean[b][:] / L (bf16 dmem). */
+int mmst_real_data_rows_bwd(const void* dlogits, const void* mean, float* d_extra, float* mean32, float* dbias, int B,
+                            int T, void* stream);
+int mmst_seq_mean_bwd_add(const float* dmean, void* dmem, int B, int L, void* stream);
+
 /* One decode step's token selection (softmax(logits/temperature), argmax, its probability) on the LAST
  * position: validate_generate_MMT_v15_4.py:754-762 / models_MMT_v15_4.py:1246-1256.  logits [B][T][ldl]. */
 int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float temperature, int64_t* next_tok,
@@ -316,6 +327,77 @@ int mmst_clip_loss(const float* logits, const float* Z, int B, float* ws, float*
 int mmst_symmetrize(const float* X, float* out, int B, void* stream);
 /* backward of torch.mean(memory, dim=0) (models_MMT_v15_4.py:946): dmem[b][l][:] = dmean[b][:] / L, bf16 out */
 int mmst_seq_mean_bwd(const float* dmean, void* dmem, int B, int L, void* stream);
+
+/* ---- one whole training step in ONE call ----
+ * What TransformerMultiGPU.training_step + the optimizer do for one batch (models_MMT_v15_4.py:1051-1118, :1213-1214)
+ * with gen_SMI_sequence off: embeddings, modality encoders, cross encoder, fingerprint head, target embedding,
+ * decoder, vocabulary projection, CrossEntropyLoss, the whole backward pass on two streams, AdamW and the refresh of
+ * the bf16 / transposed weight copies.  The launch sequence is exactly the one a caller gets by calling the entry
+ * points above layer by layer; this entry point exists because ~330 launches per step issued one by one through a
+ * foreign-function interface cost more host time than the GPU needs to run them.
+ *
+ * mmst_step_plan describes the buffers of one (batch size, target length, training_mode) and is built once;
+ * mmst_step_args carries what changes per step (input pointers, seeds, optimizer scalars). */
+#define MMST_MAX_LAYERS 8
+#define MMST_MAX_RANGES 16
+#define MMST_MAX_FFN 128
+enum { MMST_SEG_DECODER = 0, MMST_SEG_CROSS = 1, MMST_SEG_EMBED = 2, MMST_SEG_MODAL0 = 16 /* + encoder depth */ };
+
+typedef struct {
+  int B, T, L;                       /* molecules, target positions (tokens - 1), memory rows per molecule */
+  int n_groups, n_enc_layers, n_dec_layers, cross_heads;
+  int vocab, in_size, fingerprint_size;
+  /* embeddings: groups / shared as for mmst_embed_fwd, input pointers (src, mask, *_tok, *_mask, mw) left NULL */
+  mmst_embed_group embed_g[MMST_MAX_GROUPS];
+  mmst_embed_shared embed_s;
+  int ir_group;                      /* index of the IR group, or -1 */
+  void* ir_bf16;                     /* [B][1000] bf16 staging of the IR spectrum */
+  const void* ir_w; const float* ir_b; float* ir_dw; float* ir_db;   /* Linear(1000 -> 128) */
+  void* dxseq[MMST_MAX_GROUPS];      /* gradient at each group's input sequence */
+  /* encoder / decoder layers: arrays as for the layer entry points (modal_*[l] has n_groups elements) */
+  const mmst_enc_params* modal_p[MMST_MAX_LAYERS]; const mmst_enc_grads* modal_g[MMST_MAX_LAYERS];
+  const mmst_enc_acts* modal_a[MMST_MAX_LAYERS]; const mmst_enc_bwd* modal_w[MMST_MAX_LAYERS];
+  const mmst_enc_params* cross_p[MMST_MAX_LAYERS]; const mmst_enc_grads* cross_g[MMST_MAX_LAYERS];
+  const mmst_enc_acts* cross_a[MMST_MAX_LAYERS]; const mmst_enc_bwd* cross_w[MMST_MAX_LAYERS];
+  const mmst_dec_params* dec_p[MMST_MAX_LAYERS]; const mmst_dec_grads* dec_g[MMST_MAX_LAYERS];
+  const mmst_dec_acts* dec_a[MMST_MAX_LAYERS]; const mmst_dec_bwd* dec_w[MMST_MAX_LAYERS];
+  /* in the *_w structs dz2 / dz3 is the layer's incoming gradient; *_dzd[l][i] is the buffer that holds the same
+   * gradient through the residual-dropout mask (used as dzd2 / dzd3 when dropout is on) */
+  void* modal_dzd[MMST_MAX_LAYERS][MMST_MAX_GROUPS]; void* cross_dzd[MMST_MAX_LAYERS]; void* dec_dzd[MMST_MAX_LAYERS];
+  /* heads */
+  const void* memory; void* mean; const void* fp1_w; const float* fp1_b; float* fingerprint;
+  void* trg_emb; const float* embed_trg; const float* pe_trg; float* d_embed_trg; float* d_pe_trg;
+  const void* fc_out_w; const float* fc_out_b; float* d_fc_out_w; float* d_fc_out_b;   /* 64-row padded */
+  float* logits; void* dlogits; float* loss;     /* [B*T][64] fp32, [B*T][64] bf16, [1] */
+  void* dmem; void* dmem_in; void* dtrg;         /* gradients at the memory (decoder side / encoder side), target rows */
+  /* flat parameter buffers and the ranges of them that are active in this training_mode */
+  float* P; float* G; float* M; float* V; void* Pb; void* PbT;
+  int n_ranges; long range_lo[MMST_MAX_RANGES]; long range_hi[MMST_MAX_RANGES];
+  int n_ffn; uint32_t ffn1_off[MMST_MAX_FFN]; uint32_t ffn2_off[MMST_MAX_FFN];   /* linear1 / linear2 offsets in Pb */
+} mmst_step_plan;
+
+typedef struct {
+  const float* src[MMST_MAX_GROUPS]; const float* mask[MMST_MAX_GROUPS];   /* per group, NULL for the IR group */
+  const float* src_ir;                /* [B][1000] fp32 */
+  const int64_t* mf_tok; const float* mf_mask; const int64_t* ms_tok; const float* ms_mask; const float* mw;
+  int mf_bool, ms_bool, mod_bool, glob_bool;   /* mask semantics of this batch, as in mmst_embed_group / _shared */
+  const int64_t* trg; int trg_ld;     /* trg_enc_SMI [B][trg_ld] batch-first; input = columns 0..T-1, targets 1..T */
+  uint32_t step_seed;                 /* dropout stream of this step */
+  float drop_layers, drop_embed;      /* 0.1 / config.drop_out in train mode, 0 in eval mode */
+  int zero_grads;                     /* nonzero: clear the active ranges of G first */
+  float loss_grad_scale;
+  int adam_step;                      /* >= 1: AdamW with this step count after backward; 0: leave the weights alone */
+  float lr, beta1, beta2, eps, weight_decay, grad_scale;
+  /* called (on the calling thread) when every launch that writes a gradient segment has been enqueued: the caller
+   * may start that segment's all-reduce; NULL for a single rank */
+  void (*on_segment)(int segment, void* user); void* user;
+} mmst_step_args;
+
+/* `stream` carries the forward pass and the critical path of backward, `wstream` (a different stream) the parameter
+ * gradients; on return both have been joined into `stream`. */
+int mmst_train_step(const mmst_step_plan* plan, const mmst_step_args* args, void* stream, void* wstream);
+int mmst_sizeof_step_plan(void);
+int mmst_sizeof_step_args(void);
 
 int mmst_version(void);
 

@@ -91,7 +91,9 @@ def lib():
                 _lib.mmst_sizeof_attn_batch() != C.sizeof(AttnBatch) or \
                 _lib.mmst_sizeof_ffn_batch() != C.sizeof(FfnBatch) or \
                 _lib.mmst_sizeof_ffn_wgrad_batch() != C.sizeof(FfnWgradBatch) or \
-                _lib.mmst_sizeof_dec_stack_step() != C.sizeof(DecStackStep):
+                _lib.mmst_sizeof_dec_stack_step() != C.sizeof(DecStackStep) or \
+                _lib.mmst_sizeof_step_plan() != C.sizeof(StepPlan) or \
+                _lib.mmst_sizeof_step_args() != C.sizeof(StepArgs):
             raise MMSTError("struct layout mismatch between _lib.py and libmmst.so")
     return _lib
 
@@ -188,3 +190,43 @@ class EmbedShared(C.Structure):
                 _ptrs("ms_tok", "ms_mask", "ms_table", "d_ms_table") + [("has_ms", C.c_int), ("ms_bool", C.c_int)] +
                 _ptrs("mw", "mw_w", "mw_b", "d_mw_w", "d_mw_b") + [("has_mw", C.c_int), ("B", C.c_int),
                                                                     ("glob_bool", C.c_int)])
+
+
+# ---------------------------------------------------------------------------------------------
+# whole training step (mmst_train_step)
+# ---------------------------------------------------------------------------------------------
+MAX_LAYERS, MAX_RANGES, MAX_FFN = 8, 16, 128
+SEG_DECODER, SEG_CROSS, SEG_EMBED, SEG_MODAL0 = 0, 1, 2, 16
+
+
+def _layer_ptrs(*names):
+    return [(n, C.c_void_p * MAX_LAYERS) for n in names]
+
+
+class StepPlan(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("B", "T", "L", "n_groups", "n_enc_layers", "n_dec_layers", "cross_heads",
+                                        "vocab", "in_size", "fingerprint_size")] +
+                [("embed_g", EmbedGroup * MAX_GROUPS), ("embed_s", EmbedShared), ("ir_group", C.c_int)] +
+                _ptrs("ir_bf16", "ir_w", "ir_b", "ir_dw", "ir_db") + [("dxseq", C.c_void_p * MAX_GROUPS)] +
+                _layer_ptrs("modal_p", "modal_g", "modal_a", "modal_w", "cross_p", "cross_g", "cross_a", "cross_w",
+                            "dec_p", "dec_g", "dec_a", "dec_w") +
+                [("modal_dzd", (C.c_void_p * MAX_GROUPS) * MAX_LAYERS)] + _layer_ptrs("cross_dzd", "dec_dzd") +
+                _ptrs("memory", "mean", "fp1_w", "fp1_b", "fingerprint", "trg_emb", "embed_trg", "pe_trg", "d_embed_trg",
+                      "d_pe_trg", "fc_out_w", "fc_out_b", "d_fc_out_w", "d_fc_out_b", "logits", "dlogits", "loss",
+                      "dmem", "dmem_in", "dtrg", "P", "G", "M", "V", "Pb", "PbT") +
+                [("n_ranges", C.c_int), ("range_lo", C.c_long * MAX_RANGES), ("range_hi", C.c_long * MAX_RANGES),
+                 ("n_ffn", C.c_int), ("ffn1_off", C.c_uint32 * MAX_FFN), ("ffn2_off", C.c_uint32 * MAX_FFN)])
+
+
+SEGMENT_CALLBACK = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+
+class StepArgs(C.Structure):
+    _fields_ = ([("src", C.c_void_p * MAX_GROUPS), ("mask", C.c_void_p * MAX_GROUPS)] +
+                _ptrs("src_ir", "mf_tok", "mf_mask", "ms_tok", "ms_mask", "mw") +
+                [(n, C.c_int) for n in ("mf_bool", "ms_bool", "mod_bool", "glob_bool")] +
+                [("trg", C.c_void_p), ("trg_ld", C.c_int), ("step_seed", C.c_uint32), ("drop_layers", C.c_float),
+                 ("drop_embed", C.c_float), ("zero_grads", C.c_int), ("loss_grad_scale", C.c_float),
+                 ("adam_step", C.c_int)] +
+                [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")] +
+                [("on_segment", SEGMENT_CALLBACK), ("user", C.c_void_p)])

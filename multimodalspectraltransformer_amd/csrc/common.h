@@ -36,6 +36,15 @@ extern thread_local hipEvent_t mmst_armed_stop_event;   // defined in gemm.hip
     if (e__ != hipSuccess) return MMST_ERR_LAUNCH;  \
   } while (0)
 
+// Host-side helpers shared between the entry-point files.
+// `to` (if not null) waits for everything enqueued on `from` so far; events come from a per-device ring (layers.hip).
+int mmst_stream_fork(hipStream_t from, hipStream_t to);
+// target-embedding launchers with explicit token strides (misc.hip)
+int launch_trg_embed_fwd(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos, void* out,
+                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream);
+int launch_trg_embed_bwd(const int64_t* tok, int tok_ld, int tok_bs, const void* dout, float* d_embed, float* d_pos,
+                         int B, int T, int V, float drop_p, uint32_t seed, hipStream_t stream);
+
 // Counter-based dropout: one 32-bit mix per PAIR of elements, 16 bits each.
 // keep(idx) == true with probability 1 - thr/65536.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

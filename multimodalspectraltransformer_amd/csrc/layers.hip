@@ -343,6 +343,15 @@ int wait_for(hipStream_t to, hipEvent_t ev) {
 
 }  // namespace
 
+// `to` waits for everything enqueued on `from` so far.  Either may be the default stream (a null handle), so unlike
+// stream_fork() a null `to` is a stream to wait on, not "nobody waits".
+int mmst_stream_fork(hipStream_t from, hipStream_t to) {
+  hipEvent_t ev = ring_event();
+  if (!ev || from == to) return MMST_ERR_LAUNCH;
+  if (hipEventRecord(ev, from) != hipSuccess) return MMST_ERR_LAUNCH;
+  return hipStreamWaitEvent(to, ev, 0) == hipSuccess ? MMST_OK : MMST_ERR_LAUNCH;
+}
+
 extern "C" {
 
 // ---- encoder layer backward, critical path: gradients of activations only ----

@@ -176,13 +176,14 @@ __global__ void seq_mean_kernel(const bf16* mem, bf16* out, int L) {
   }
 }
 
-__global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, const float* embed, const float* pos, bf16* out,
-                                     int B, int T, float drop_p, uint32_t seed) {
+// token of (position t, sequence b) = tok[t * tok_ld + b * tok_bs]: (T, B) row-major is (B, 1), batch-first (B, 64) is (1, 64)
+__global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos,
+                                     bf16* out, int B, int T, float drop_p, uint32_t seed) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = gid >> 4, c0 = (gid & 15) * 8;
   if (row >= B * T) return;
   const int b = row / T, t = row % T;
-  const int64_t tk = tok[(size_t)t * tok_ld + b];
+  const int64_t tk = tok[(size_t)t * tok_ld + (size_t)b * tok_bs];
   const uint32_t thr = drop_threshold(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   bf16x8 o;
@@ -195,13 +196,14 @@ __global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, const float
   *reinterpret_cast<bf16x8*>(out + (size_t)row * D + c0) = o;
 }
 
-// Gradient of the two target-embedding tables without atomics: one workgroup per table row,
-// 8 row-groups x 128 columns per workgroup, token ids staged in LDS.
-// blocks [0, T)      : d_pos[t]  += sum over the batch of dout[b][t]
-// blocks [T, T + V)  : d_embed[v] += sum over every (b, t) whose token is v
-__global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16* dout, float* d_embed, float* d_pos,
-                                     int B, int T, int V, float drop_p, uint32_t seed) {
-  __shared__ short toks[8192];
+// Gradient of the two target-embedding tables: one workgroup per (table row, slice of the token rows), 8 row-groups
+// x 128 columns per workgroup, token ids staged in LDS; the EMB_SLICES partial sums of a table row meet in fp32 atomics.
+// blocks [0, T)                    : d_pos[t]  += sum over the batch of dout[b][t]
+// blocks [T, T + V * EMB_SLICES)   : d_embed[v] += sum over the (b, t) of one slice whose token is v
+#define EMB_SLICES 8
+__global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, int tok_bs, const bf16* dout, float* d_embed,
+                                     float* d_pos, int B, int T, int V, float drop_p, uint32_t seed) {
+  __shared__ short toks[1024];
   __shared__ float red[8][D];
   const int c = threadIdx.x & (D - 1), grp = threadIdx.x >> 7;
   const uint32_t thr = drop_threshold(drop_p);
@@ -217,13 +219,15 @@ __global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16*
       acc += g;
     }
   } else {
-    const int v = blockIdx.x - T;
-    for (int base = 0; base < rows; base += 8192) {
-      const int n = min(8192, rows - base);
+    const int v = (blockIdx.x - T) / EMB_SLICES, slice = (blockIdx.x - T) % EMB_SLICES;
+    const int per = (rows + EMB_SLICES - 1) / EMB_SLICES;
+    const int lo = slice * per, hi = min(rows, lo + per);
+    for (int base = lo; base < hi; base += 1024) {
+      const int n = min(1024, hi - base);
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int row = base + i;
-        toks[i] = (short)tok[(size_t)(row % T) * tok_ld + row / T];
+        toks[i] = (short)tok[(size_t)(row % T) * tok_ld + (size_t)(row / T) * tok_bs];
       }
       __syncthreads();
       for (int i = grp; i < n; i += 8) {
@@ -242,8 +246,36 @@ __global__ void trg_embed_bwd_kernel(const int64_t* tok, int tok_ld, const bf16*
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += red[i][c];
     if ((int)blockIdx.x < T) d_pos[(size_t)blockIdx.x * D + c] += s;
-    else d_embed[(size_t)(blockIdx.x - T) * D + c] += s;
+    else if (s != 0.f) atomicAdd(d_embed + (size_t)((blockIdx.x - T) / EMB_SLICES) * D + c, s);
   }
+}
+
+// use_real_data branch (models_MMT_v15_4.py:965-971): logits <- (logits + extra[b]) / 2, extra = real_data_linear(mean)
+__global__ void real_data_mix_kernel(float* logits, const float* extra, int T, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long b = i / ((long)T * 64);
+  logits[i] = 0.5f * (logits[i] + extra[b * 64 + (i & 63)]);
+}
+// its backward, row part: d_extra[b][c] = sum_t dlogits[b][t][c] (dlogits already carries the factor 1/2),
+// db[c] += d_extra[b][c], and an fp32 copy of mean[b] for the fp32 products that follow.  One block of 128 threads per b.
+__global__ void real_data_rows_kernel(const bf16* dlogits, const bf16* mean, float* d_extra, float* mean32, float* db,
+                                      int T) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  mean32[(size_t)b * D + c] = (float)mean[(size_t)b * D + c];
+  if (c < 64) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += (float)dlogits[((size_t)b * T + t) * 64 + c];
+    d_extra[(size_t)b * 64 + c] = s;
+    if (s != 0.f) atomicAdd(db + c, s);
+  }
+}
+// dmem[b][l][:] += dmean[b][:] / L  (gradient of torch.mean(memory, dim=0) added to an existing memory gradient)
+__global__ void seq_mean_bwd_add_kernel(const float* dmean, bf16* dmem, int L, long n) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const long b = o / ((long)L * D);
+  dmem[o] = (bf16)((float)dmem[o] + dmean[b * D + (o & (D - 1))] / L);
 }
 
 // one wave per row of logits (V <= 64), rows strided over the grid
@@ -376,6 +408,26 @@ int fill_embed_args(EmbedArgs& A, int n, const mmst_embed_group* g, const mmst_e
 
 }  // namespace
 
+// target-embedding launchers with a token stride per position and per sequence (see trg_embed_fwd_kernel)
+int launch_trg_embed_fwd(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos, void* out,
+                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!tok || !embed || !pos || !out || B < 1 || T < 1) return MMST_ERR_ARG;
+  const int threads = B * T * 16;
+  hipLaunchKernelGGL(trg_embed_fwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, tok, tok_ld, tok_bs,
+                     embed, pos, (bf16*)out, B, T, drop_p, seed);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int launch_trg_embed_bwd(const int64_t* tok, int tok_ld, int tok_bs, const void* dout, float* d_embed, float* d_pos,
+                         int B, int T, int V, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1 || V < 1) return MMST_ERR_ARG;
+  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3(T + V * EMB_SLICES), dim3(8 * D), 0, stream, tok, tok_ld, tok_bs,
+                     (const bf16*)dout, d_embed, d_pos, B, T, V, drop_p, seed);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
 extern "C" {
 
 int mmst_embed_fwd(int n, const mmst_embed_group* g, const mmst_embed_shared* s, void* stream) {
@@ -412,19 +464,37 @@ int mmst_seq_mean(const void* mem, void* out, int B, int L, void* stream) {
 
 int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const float* pos, void* out, int B, int T,
                        float drop_p, uint32_t seed, void* stream) {
-  if (!tok || !embed || !pos || !out || B < 1 || T < 1) return MMST_ERR_ARG;
-  const int threads = B * T * 16;
-  hipLaunchKernelGGL(trg_embed_fwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
-                     embed, pos, (bf16*)out, B, T, drop_p, seed);
-  MMST_CHECK_LAUNCH();
-  return MMST_OK;
+  return launch_trg_embed_fwd(tok, tok_ld, 1, embed, pos, out, B, T, drop_p, seed, (hipStream_t)stream);
 }
 
 int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
                        int V, float drop_p, uint32_t seed, void* stream) {
-  if (!tok || !dout || !d_embed || !d_pos || B < 1 || T < 1 || V < 1) return MMST_ERR_ARG;
-  hipLaunchKernelGGL(trg_embed_bwd_kernel, dim3(T + V), dim3(8 * D), 0, (hipStream_t)stream, tok, tok_ld,
-                     (const bf16*)dout, d_embed, d_pos, B, T, V, drop_p, seed);
+  return launch_trg_embed_bwd(tok, tok_ld, 1, dout, d_embed, d_pos, B, T, V, drop_p, seed, (hipStream_t)stream);
+}
+
+int mmst_real_data_mix(float* logits, const float* extra, int B, int T, void* stream) {
+  if (!logits || !extra || B < 1 || T < 1) return MMST_ERR_ARG;
+  const long n = (long)B * T * 64;
+  hipLaunchKernelGGL(real_data_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                     extra, T, n);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_real_data_rows_bwd(const void* dlogits, const void* mean, float* d_extra, float* mean32, float* dbias, int B,
+                            int T, void* stream) {
+  if (!dlogits || !mean || !d_extra || !mean32 || !dbias || B < 1 || T < 1) return MMST_ERR_ARG;
+  hipLaunchKernelGGL(real_data_rows_kernel, dim3(B), dim3(D), 0, (hipStream_t)stream, (const bf16*)dlogits,
+                     (const bf16*)mean, d_extra, mean32, dbias, T);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_seq_mean_bwd_add(const float* dmean, void* dmem, int B, int L, void* stream) {
+  if (!dmean || !dmem || B < 1 || L < 1) return MMST_ERR_ARG;
+  const long n = (long)B * L * D;
+  hipLaunchKernelGGL(seq_mean_bwd_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmean,
+                     (bf16*)dmem, L, n);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

@@ -100,6 +100,7 @@ class Arena:
             view.copy_(p.data)
             p.data = view
         self.named = named
+        self.use_real_data = bool(getattr(model.config, "use_real_data", False))
         self.shadow_stale = True
         self.weights_serial = 0        # counts rewrites of the bf16 weight copy (caches of projected tensors key on it)
         self.transposed_ready = None   # event after the last refresh of PbT on another stream than the caller's
@@ -153,7 +154,9 @@ class Arena:
                 tags.add(t)
         out = []
         for k in self.order:
-            if k.startswith("fp1.") or k.startswith("real_data_linear."):
+            if k.startswith("fp1.") or (k.startswith("real_data_linear.") and not self.use_real_data):
+                continue
+            if not self.named[k].requires_grad:   # frozen (MT_functions_v15_4.py:124-133 freezes all but real_data_linear)
                 continue
             skip = False
             for t in ALL_MODS:
@@ -314,6 +317,9 @@ class Plan:
         self.logits = cv.take(M * VPAD, f32)
         self.dlogits = cv.take(M * VPAD)
         self.loss = cv.take(1, f32)
+        # use_real_data branch: real_data_linear(mean) [B][64], its gradient, fp32 mean, gradient at the mean
+        self.rd_extra, self.rd_dextra = cv.take(B * VPAD, f32), cv.take(B * VPAD, f32)
+        self.rd_mean32, self.rd_dmean = cv.take(B * D, f32), cv.take(B * D, f32)
         self.next_prob = cv.take((m.max_len + 1) * B, f32)
 
         # backward scratch: one set PER LAYER, never reused inside a step, so the weight-gradient launches
@@ -651,6 +657,31 @@ class Engine:
         out = pl.dec_acts[m.num_decoder_layers - 1]["y"]
         ops.gemm([dict(P=_P(out), Q=ar.pb("fc_out.weight"), C=_P(pl.logits), bias=ar.p32("fc_out.bias"),
                        ldp=D, ldq=D, ldc=VPAD, Pn=B * T, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
+        if getattr(m.config, "use_real_data", False):
+            # models_MMT_v15_4.py:965-971: logits = (fc_out(decoder) + real_data_linear(mean(memory))) / 2
+            ops.gemm([dict(P=_P(pl.mean), Q=ar.pb("real_data_linear.weight"), C=_P(pl.rd_extra),
+                           bias=ar.p32("real_data_linear.bias"), ldp=D, ldq=D, ldc=VPAD, Pn=B, Qn=VPAD, K=D,
+                           flags=L.GF_OUT_F32)], L.EPI_BIAS)
+            L.check(lib.mmst_real_data_mix(C.c_void_p(_P(pl.logits)), C.c_void_p(_P(pl.rd_extra)), B, T, st),
+                    "mmst_real_data_mix")
+
+    def real_data_backward(self, pl, into_memory=True):
+        """Backward of the use_real_data branch from pl.dlogits (which must already carry the factor 1/2 of the
+        average): gradients of real_data_linear and, if into_memory, the gradient at mean(memory) in pl.rd_dmean."""
+        lib, st, ar, B, T = L.lib(), L.stream_ptr(), self.arena, pl.B, pl.T
+        vp = C.c_void_p
+        L.check(lib.mmst_real_data_rows_bwd(vp(_P(pl.dlogits)), vp(_P(pl.mean)), vp(_P(pl.rd_dextra)),
+                                            vp(_P(pl.rd_mean32)), vp(ar.g32("real_data_linear.bias")), B, T, st),
+                "mmst_real_data_rows_bwd")
+        one, zero = C.c_float(1.0), C.c_float(0.0)
+        # dW[c][j] += sum_b d_extra[b][c] mean[b][j]
+        L.check(lib.mmst_sgemm(vp(_P(pl.rd_dextra)), C.c_long(1), C.c_long(VPAD), vp(_P(pl.rd_mean32)), C.c_long(D),
+                               C.c_long(1), vp(ar.g32("real_data_linear.weight")), D, None, VPAD, D, B, one, one, st),
+                "mmst_sgemm")
+        if into_memory:   # d_mean[b][j] = sum_c d_extra[b][c] W[c][j]
+            L.check(lib.mmst_sgemm(vp(_P(pl.rd_dextra)), C.c_long(VPAD), C.c_long(1),
+                                   vp(ar.p32("real_data_linear.weight")), C.c_long(D), C.c_long(1), vp(_P(pl.rd_dmean)),
+                                   D, None, B, D, VPAD, one, zero, st), "mmst_sgemm")
 
     def ce_loss(self, pl, trg_enc_SMI, grad_scale=1.0, want_grad=True):
         """CrossEntropyLoss over all positions (PAD included); fills pl.dlogits."""
@@ -662,6 +693,146 @@ class Engine:
                                  trg.shape[1], pl.B, pl.T, C.c_void_p(_P(pl.loss)),
                                  C.c_void_p(_P(pl.dlogits)) if want_grad else None, C.c_float(grad_scale), st),
                 "mmst_ce_loss")
+        return pl.cv.view(pl.loss, 1)
+
+    # ------------------------------------------------------------------
+    def step_plan(self, pl):
+        """The C description of `pl` for mmst_train_step (built once per plan; the ctypes arrays of the plan stay
+        referenced from it)."""
+        sp = getattr(pl, "_step_plan", None)
+        if sp is not None:
+            return sp
+        m, ar = self.model, self.arena
+        nl, ndl, n = m.num_encoder_layers, m.num_decoder_layers, pl.n_groups
+        if nl > L.MAX_LAYERS or ndl > L.MAX_LAYERS:
+            raise L.MMSTError(f"mmst_train_step supports at most {L.MAX_LAYERS} layers per stack")
+        sp = L.StepPlan()
+        sp.B, sp.T, sp.L, sp.n_groups = pl.B, max(pl.T, 1), pl.Lmem, n
+        sp.n_enc_layers, sp.n_dec_layers, sp.cross_heads = nl, ndl, m.cross_heads
+        sp.vocab, sp.in_size, sp.fingerprint_size = m.out_size, m.config.in_size, m.fingerprint_size
+        sp.ir_group = -1
+        for i, (name, S, off) in enumerate(pl.mods):
+            g = sp.embed_g[i]
+            g.xseq, g.kbias, g.kbias_glob = _P(pl.xseq[name]), _P(pl.kbias[name]), _P(pl.kbias_glob)
+            g.S, g.L_glob, g.off_glob = S, pl.Lmem, off
+            key = _EMB_KEYS[name]
+            if name == "IR":
+                g.in_dim, g.n_spec, g.ir_dpre = 0, 1, _P(pl.ir_dpre)
+                sp.ir_group = i
+                sp.ir_bf16 = _P(pl.ir_bf16)
+                sp.ir_w, sp.ir_b = ar.pb(key + ".weight"), ar.p32(key + ".bias")
+                sp.ir_dw, sp.ir_db = ar.g32(key + ".weight"), ar.g32(key + ".bias")
+            else:
+                g.in_dim, g.n_spec = (1 if name == "13C" else 2), 64
+                g.w, g.b = ar.p32(key + ".weight"), ar.p32(key + ".bias")
+                g.dw, g.db = ar.g32(key + ".weight"), ar.g32(key + ".bias")
+            sp.dxseq[i] = _P(pl.dxseq[i])
+        es = sp.embed_s
+        es.B = pl.B
+        es.has_mf, es.has_ms, es.has_mw = int(pl.has_mf), int(pl.has_ms), int(pl.has_mw)
+        if pl.has_mf:
+            es.mf_table = ar.p32("linear_embedding_MF.embedding.weight")
+            es.d_mf_table = ar.g32("linear_embedding_MF.embedding.weight")
+        if pl.has_ms:
+            es.ms_table = ar.p32("linear_embedding_MS.embedding.weight")
+            es.d_ms_table = ar.g32("linear_embedding_MS.embedding.weight")
+        if pl.has_mw:
+            k = "linear_embedding_MW.linear_spec_embedding_MW"
+            es.mw_w, es.mw_b = ar.p32(k + ".weight"), ar.p32(k + ".bias")
+            es.d_mw_w, es.d_mw_b = ar.g32(k + ".weight"), ar.g32(k + ".bias")
+        adr = C.addressof
+        for l in range(nl):
+            sp.modal_p[l], sp.modal_g[l] = adr(pl.modal_p[l]), adr(pl.modal_g[l])
+            sp.modal_a[l], sp.modal_w[l] = adr(pl.modal_a[l]), adr(pl.modal_w[l])
+            sp.cross_p[l], sp.cross_g[l] = adr(pl.cross_p[l]), adr(pl.cross_g[l])
+            sp.cross_a[l], sp.cross_w[l] = adr(pl.cross_a[l]), adr(pl.cross_w[l])
+            for i in range(n):
+                sp.modal_dzd[l][i] = pl.modal_dzd[l][i][1]
+            sp.cross_dzd[l] = pl.cross_dzd[l][1]
+        for l in range(ndl):
+            sp.dec_p[l], sp.dec_g[l] = adr(pl.dec_p[l]), adr(pl.dec_g[l])
+            sp.dec_a[l], sp.dec_w[l] = adr(pl.dec_a[l]), adr(pl.dec_w[l])
+            sp.dec_dzd[l] = pl.dec_dzd[l][1]
+        sp.memory, sp.mean = _P(pl.memory), _P(pl.mean)
+        sp.fp1_w, sp.fp1_b, sp.fingerprint = ar.pb("fp1.weight"), ar.p32("fp1.bias"), _P(pl.fingerprint)
+        sp.trg_emb = _P(pl.trg_emb)
+        sp.embed_trg, sp.pe_trg = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
+        sp.d_embed_trg, sp.d_pe_trg = ar.g32("embed_trg.weight"), ar.g32("pe_trg.weight")
+        sp.fc_out_w, sp.fc_out_b = ar.pb("fc_out.weight"), ar.p32("fc_out.bias")
+        sp.d_fc_out_w, sp.d_fc_out_b = ar.g32("fc_out.weight"), ar.g32("fc_out.bias")
+        sp.logits, sp.dlogits, sp.loss = _P(pl.logits), _P(pl.dlogits), _P(pl.loss)
+        sp.dmem, sp.dmem_in, sp.dtrg = _P(pl.dmem), _P(pl.dmem_in), _P(pl.dtrg)
+        if ar.M is None:
+            ar.M, ar.V = torch.zeros_like(ar.P), torch.zeros_like(ar.P)
+        sp.P, sp.G, sp.M, sp.V = ar.P.data_ptr(), ar.G.data_ptr(), ar.M.data_ptr(), ar.V.data_ptr()
+        sp.Pb, sp.PbT = ar.Pb.data_ptr(), ar.PbT.data_ptr()
+        ranges = ar.active_ranges(pl.mode)
+        if len(ranges) > L.MAX_RANGES or len(ar.ffn1_offsets) > L.MAX_FFN:
+            raise L.MMSTError("too many parameter ranges / feed-forward blocks for mmst_train_step")
+        sp.n_ranges = len(ranges)
+        for i, (lo, hi) in enumerate(ranges):
+            sp.range_lo[i], sp.range_hi[i] = lo, hi
+        sp.n_ffn = len(ar.ffn1_offsets)
+        for i, (o1, o2) in enumerate(zip(ar.ffn1_offsets, ar.ffn2_offsets)):
+            sp.ffn1_off[i], sp.ffn2_off[i] = o1, o2
+        pl._step_plan = sp
+        pl._step_args = L.StepArgs()
+        return sp
+
+    def train_step(self, pl, batch, train=True, zero_grads=True, adam=None, grad_scale=1.0, loss_grad_scale=1.0,
+                   on_segment=None):
+        """forward + CE + backward (+ AdamW when `adam` = (step count, lr, betas, eps, weight decay)) of one batch in ONE
+        call into the library (mmst_train_step).  Same launches as encode() / decode() / ce_loss() / backward() and
+        FusedAdamW.step(); returns the loss as a view of the plan's loss slot."""
+        sp = self.step_plan(pl)
+        a = pl._step_args
+        keep = []
+
+        def dev(t, dtype):
+            t = t.to(device=self.device, dtype=dtype)
+            t = t if t.is_contiguous() else t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        f32 = torch.float32
+        mf_mask, ms_mask = batch.get("mask_MF"), batch.get("mask_MS")
+        mf_bool = bool(pl.has_mf and mf_mask is not None and mf_mask.dtype == torch.bool)
+        ms_bool = bool(pl.has_ms and ms_mask is not None and ms_mask.dtype == torch.bool)
+        comps_bool = (not pl.has_mf or mf_bool) and (not pl.has_ms or ms_bool)
+        glob_bool = comps_bool and all(name == "IR" for name, _, _ in pl.blank)
+        for i, (name, S, off) in enumerate(pl.mods):
+            if name == "IR":
+                a.src[i], a.mask[i] = None, None
+                a.src_ir = dev(batch["src_IR"], f32)
+            else:
+                a.src[i], a.mask[i] = dev(batch["src_" + name], f32), dev(batch["mask_" + name], f32)
+        if pl.has_mf:
+            a.mf_tok, a.mf_mask = dev(batch["src_MF"], torch.int64), dev(mf_mask, f32)
+        if pl.has_ms:
+            a.ms_tok, a.ms_mask = dev(batch["src_MS"], torch.int64), dev(ms_mask, f32)
+        if pl.has_mw:
+            a.mw = dev(batch["trg_MW"].reshape(-1), f32)
+        a.mf_bool, a.ms_bool, a.mod_bool, a.glob_bool = int(mf_bool), int(ms_bool), int(comps_bool), int(glob_bool)
+        trg = batch["trg_enc_SMI"]
+        a.trg, a.trg_ld = dev(trg, torch.int64), trg.shape[1]
+        a.step_seed = self.step_seed & 0xFFFFFFFF
+        a.drop_layers = LAYER_DROPOUT if train else 0.0
+        a.drop_embed = float(self.model.config.drop_out) if train else 0.0
+        a.zero_grads, a.loss_grad_scale = int(zero_grads), float(loss_grad_scale)
+        if adam is None:
+            a.adam_step = 0
+        else:
+            a.adam_step, a.lr, (a.beta1, a.beta2), a.eps, a.weight_decay = adam
+        a.grad_scale = float(grad_scale)
+        cb = L.SEGMENT_CALLBACK(on_segment) if on_segment is not None else L.SEGMENT_CALLBACK()
+        a.on_segment = cb
+        main = torch.cuda.current_stream()
+        ws = self._side_stream(main)
+        pl.mask_is_bool = glob_bool
+        pl.encode_serial = getattr(pl, "encode_serial", 0) + 1
+        pl._step_keep = (keep, cb)     # inputs stay referenced until the next step has been enqueued
+        L.check(L.lib().mmst_train_step(C.byref(sp), C.byref(a), C.c_void_p(main.cuda_stream),
+                                        C.c_void_p(ws.cuda_stream)), "mmst_train_step")
         return pl.cv.view(pl.loss, 1)
 
     def _side_stream(self, main):
@@ -704,6 +875,8 @@ class Engine:
                     "mmst_encoder_layer_bwd_streams")
 
         if not skip_decoder:
+            if getattr(m.config, "use_real_data", False):
+                self.real_data_backward(pl)
             # vocabulary projection
             last = pl.dec_acts[ndl - 1]
             sc = pl.dec_bwd[ndl - 1]
@@ -741,6 +914,10 @@ class Engine:
                                            C.c_void_p(ar.g32("embed_trg.weight")), C.c_void_p(ar.g32("pe_trg.weight")),
                                            B, T, m.config.in_size, C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)),
                                            wst), "mmst_trg_embed_bwd")
+            if getattr(m.config, "use_real_data", False):
+                # the gradient at mean(memory) joins the decoder's memory gradient before the cross encoder reads it
+                L.check(lib.mmst_seq_mean_bwd_add(C.c_void_p(_P(pl.rd_dmean)), C.c_void_p(_P(pl.dmem)), B, Lm, st),
+                        "mmst_seq_mean_bwd_add")
             if on_segment:
                 on_segment("decoder")
         # cross encoder

@@ -196,9 +196,14 @@ class _ForwardFn(torch.autograd.Function):
         # (T, B, V) fp32 -> internal [B*T][64] bf16
         d = pl.cv.view(pl.dlogits, pl.B, pl.T, VPAD)
         d.zero_()
-        d[:, :, :model.out_size] = dlogits.transpose(0, 1)
+        rd = bool(getattr(model.config, "use_real_data", False))
+        # use_real_data: the logits are the average of two branches, each of which sees half the gradient
+        d[:, :, :model.out_size] = dlogits.transpose(0, 1) * (0.5 if rd else 1.0)
         eng.arena.prepare_grads(pl.mode)
-        eng.backward(pl, model.training)
+        if rd and model.only_real_data_trainable():
+            eng.real_data_backward(pl, into_memory=False)   # everything else is frozen: nothing more to compute
+        else:
+            eng.backward(pl, model.training)
         return torch.zeros((), device=dlogits.device), None, None, None
 
 
@@ -357,8 +362,6 @@ class MultimodalTransformer(nn.Module):
         # a tensor of its own, (T, B, V) contiguous like the reference's: the plan's logits buffer is rewritten by the
         # next call of the same shape
         logits = pl.cv.view(pl.logits, B, T, VPAD)[:, :, :self.out_size].transpose(0, 1).contiguous()
-        if self.config.use_real_data:
-            raise L.MMSTError("use_real_data=True (real_data_linear averaging, :965-971) is not implemented")
         outs = (logits, fingerprint, memory, mask)
         self._last_plan = pl
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -366,6 +369,11 @@ class MultimodalTransformer(nn.Module):
                 self._grad_token = torch.zeros((), device=logits.device, requires_grad=True)
             outs = _ForwardFn.apply(self._grad_token, self, pl, outs)
         return outs
+
+    def only_real_data_trainable(self):
+        """The reference's fine-tuning mode for real data (MT_functions_v15_4.py:124-133): every parameter frozen
+        except real_data_linear."""
+        return all(p.requires_grad == k.startswith("real_data_linear.") for k, p in self.named_parameters())
 
     def run_encoder_half(self, batch, T=0):
         """Embeddings + modality encoders + cross encoder + fingerprint; returns the plan that holds them."""
@@ -405,8 +413,12 @@ class MultimodalTransformer(nn.Module):
         B = pl.B
         pl.cv.view(pl.tok, self.max_len + 1, B)[:T].copy_(trg.to(eng.device).t()[:-1])
         eng.decode(pl, self.training, T=T)
-        loss = eng.ce_loss(pl, trg, grad_scale=grad_scale)
-        eng.backward(pl, self.training, on_segment)
+        rd = bool(getattr(self.config, "use_real_data", False))
+        loss = eng.ce_loss(pl, trg, grad_scale=grad_scale * (0.5 if rd else 1.0))
+        if rd and self.only_real_data_trainable():
+            eng.real_data_backward(pl, into_memory=False)
+        else:
+            eng.backward(pl, self.training, on_segment)
         self._last_plan = pl
         return loss
 

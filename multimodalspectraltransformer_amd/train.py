@@ -193,22 +193,35 @@ class TransformerMultiGPU:
         if self.reducer is None or self.reducer.flat is not ar.G:
             self.reducer = GradReducer(ar.G, ar.reduce_segments(), self.world,
                                        active=ar.active_ranges(self.config.training_mode))
-        ar.G.zero_()
-        loss = model.loss_and_backward(
-            x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))
-        scale = self.reducer.finish()
-        if os.environ.get("MMST_DEBUG_REDUCE") and self.world > 1:
-            torch.cuda.synchronize()
-            mine = {k: float(ar.G[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
-            minep = {k: float(ar.P[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
-            allg, allp = [None] * self.world, [None] * self.world
-            dist.all_gather_object(allg, mine)
-            dist.all_gather_object(allp, minep)
-            badg = [k for k in ar.order if any(s[k] != allg[0][k] for s in allg)]
-            badp = [k for k in ar.order if any(s[k] != allp[0][k] for s in allp)]
-            print(f"[reduce] rank {dist.get_rank()} step {batch_idx}: {len(badg)} gradient tensors differ {badg[:3]}, "
-                  f"{len(badp)} parameter tensors differ before the update {badp[:3]}", flush=True)
-        self.optimizer.step(self.config.training_mode, grad_scale=scale)
+        if os.environ.get("MMST_C_STEP", "1") != "0" and not getattr(self.config, "use_real_data", False):
+            # the whole step in one call into the library (mmst_train_step); with several ranks the optimizer runs
+            # after the segment reductions have been waited for
+            T = x['trg_enc_SMI'].shape[1] - 1
+            first = next(x["src_" + t] for t in ("1H", "13C", "HSQC", "COSY") if t in self.config.training_mode)
+            pl = eng.plan(first.shape[0], T, self.config.training_mode)
+            opt = self.optimizer
+            adam = None
+            if self.world == 1:
+                opt.step_count += 1
+                ar.weights_serial += 1
+                adam = (opt.step_count, opt.lr, opt.betas, opt.eps, opt.wd)
+            names = {L.SEG_DECODER: "decoder", L.SEG_CROSS: "cross", L.SEG_EMBED: "embed"}
+            cb = None
+            if self.world > 1:
+                def cb(seg, user):
+                    name = names.get(seg) or f"modal_l{seg - L.SEG_MODAL0}"
+                    self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),))
+            loss = eng.train_step(pl, x, train=True, zero_grads=True, adam=adam, on_segment=cb)
+            model._last_plan = pl
+            if self.world > 1:
+                scale = self.reducer.finish()
+                self.optimizer.step(self.config.training_mode, grad_scale=scale)
+        else:
+            ar.G.zero_()
+            loss = model.loss_and_backward(
+                x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))
+            scale = self.reducer.finish()
+            self.optimizer.step(self.config.training_mode, grad_scale=scale)
         out = {'loss': loss.clone()}   # the plan's loss slot is rewritten by the next step
         self.last_train_loss = out['loss']
         self.global_step += 1
@@ -335,6 +348,12 @@ def run_training_MMT(config, batches, num_epochs=None, log=print):
     """Epoch loop of MT_functions_v15_4.py:93-158: `batches` is a callable epoch -> iterable of collated
     batch dicts for THIS rank."""
     tm = TransformerMultiGPU(config)
+    if getattr(config, "load_model", False) and getattr(config, "checkpoint_path", None):
+        tm = TransformerMultiGPU.load_from_checkpoint(config.checkpoint_path, config=config)   # MT_functions_v15_4.py:121-123
+    if getattr(config, "use_real_data", False):
+        # MT_functions_v15_4.py:124-133: fine-tuning on real data trains real_data_linear only
+        for k, p in tm.model.named_parameters():
+            p.requires_grad = k.startswith("real_data_linear.")
     tm.to(config.device)
     tm.configure_optimizers()
     for epoch in range(num_epochs or config.num_epochs):

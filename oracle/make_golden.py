@@ -99,11 +99,11 @@ def digest(t, n=96):
     return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
 
 
-def forward_case(M, name, mode, nl, B, seed, wseed, with_grads=True, steps=0, full_logits=True):
+def forward_case(M, name, mode, nl, B, seed, wseed, with_grads=True, steps=0, full_logits=True, **cfg_over):
     torch.manual_seed(0)
-    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.0)
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.0, **cfg_over)
     model = M.MultimodalTransformer(cfg)
-    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, **cfg_over)
     sd = O.make_state_dict(ocfg, wseed)
     assert list(sd.keys()) == list(model.state_dict().keys()), "state_dict key order differs"
     model.load_state_dict(sd)
@@ -455,6 +455,11 @@ def data_case(dl):
     print('data ok', out['formulas'][:3], out['mw'][:3])
 
 
+def real_data_case(M):
+    """config.use_real_data=True (models_MMT_v15_4.py:965-971): logits averaged with real_data_linear(mean(memory))."""
+    forward_case(M, 'fwd_rd_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 3, seed=17, wseed=107, use_real_data=True)
+
+
 def ckpt_case(M):
     """state_dict keys of the reference's LightningModule wrapper (what its .ckpt files hold under 'state_dict') and
     of the bare model (its .pth files), for a one-layer configuration."""
@@ -489,6 +494,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'clip':      # only the CLIP-head fixture
         clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'real_data':
+        real_data_case(M)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'ckpt':      # only the checkpoint key lists
         ckpt_case(M)
         return
@@ -507,6 +515,7 @@ def main():
     forward_case(M, 'fwd_ms_L1', '1H_13C_HSQC_COSY_IR_MF_MS_MW', 1, 2, seed=14, wseed=104)
     forward_case(M, 'fwd_nomf_L1', '1H_HSQC_COSY_IR', 1, 2, seed=15, wseed=105)
     forward_case(M, 'fwd_c2_L6', '1H_HSQC_COSY_IR_MF_MW', 6, 2, seed=16, wseed=106, with_grads=False)
+    real_data_case(M)
     ckpt_case(M)
     full_case(M)
     greedy_cases(M, vg)

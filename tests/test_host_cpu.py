@@ -129,6 +129,32 @@ def test_state_dict_keys_and_shapes_match_reference():
     assert sum(p.numel() for p in full.parameters()) == 25566294
 
 
+def test_checkpoint_layout_matches_reference_wrapper(tmp_path):
+    """The wrapper's state_dict / .ckpt layout against the key lists of the reference's LightningModule (fixture
+    ckpt_keys.json written by oracle/make_golden.py from the reference itself): 'model.'-prefixed keys in the same
+    order, same shapes; a written .ckpt loads with weights_only=True and round-trips through load_from_checkpoint."""
+    from multimodalspectraltransformer_amd.train import TransformerMultiGPU
+    want = json.load(open(os.path.join(GOLDEN, "ckpt_keys.json")))
+    cfg = O.default_cfg(num_encoder_layers=1, num_decoder_layers=1)
+    cfg.update(device="cpu", training_setup="pretraining", lr_finetuning=5e-5, model_save_dir=str(tmp_path))
+    torch.manual_seed(0)
+    tm = TransformerMultiGPU(argparse.Namespace(**cfg))
+    sd = tm.state_dict()
+    assert list(sd.keys()) == want["wrapper_keys"]
+    assert list(tm.model.state_dict().keys()) == want["model_keys"]
+    assert {k: list(v.shape) for k, v in sd.items()} == want["shapes"]
+    path = tm.save_checkpoint(str(tmp_path / "m.ckpt"))
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(raw["state_dict"].keys()) == want["wrapper_keys"] and raw["epoch"] == 0 and raw["global_step"] == 0
+    tm2 = TransformerMultiGPU.load_from_checkpoint(path, config=argparse.Namespace(**cfg))
+    for k, v in tm2.model.state_dict().items():
+        assert torch.equal(v, sd["model." + k]), k
+    pth = tm.on_epoch_end(3, 1.23456)
+    assert os.path.basename(pth) == "MultimodalTransformer_Epoch_3_Loss1.235.pth"
+    tm3 = TransformerMultiGPU.load_from_checkpoint(pth, config=argparse.Namespace(**cfg))
+    assert all(torch.equal(v, sd["model." + k]) for k, v in tm3.model.state_dict().items())
+
+
 def test_synthetic_workload_equals_oracle_generator():
     """bench.py draws its batches from the package (the oracle is test infrastructure); both generators must stay
     the same function of the seed so that the CPU baseline and the GPU run see the same workload."""

@@ -62,6 +62,21 @@ def test_gradients_match_reference(name, mode):
     assert checked > 50
 
 
+def test_use_real_data_branch_matches_reference():
+    g = load_golden("fwd_rd_L1")
+    nl = int(g["nl"])
+    cfg = O.default_cfg(training_mode="1H_HSQC_COSY_IR_MF_MW", num_encoder_layers=nl, num_decoder_layers=nl,
+                        use_real_data=True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(cfg, int(g["wseed"])).items()}
+    batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), cfg["training_mode"])
+    loss, logits, fp, memory, mask = O.training_forward(sd, cfg, batch)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], atol=2e-5, rtol=1e-4)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k in ("real_data_linear.weight", "real_data_linear.bias", "fc_out.weight", "encoder_cross.layers.0.linear1.weight"):
+        digest_close(digest(sd[k].grad), g["grad/" + k], 2e-3, 1e-7)
+
+
 def test_adamw_two_steps():
     g = load_golden("fwd_c2_L2")
     cfg, sd, batch = _setup(g, "1H_HSQC_COSY_IR_MF_MW")

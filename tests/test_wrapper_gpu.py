@@ -208,3 +208,37 @@ def test_decoder_submodule_mask_handling_and_cache():
         mem3 = torch.randn(40, 3, 128, generator=gen_).cuda()
         third = model.decoder(tgt, mem3, tgt_mask=model.generate_square_subsequent_mask(9))
         assert float((third.cpu() - O.decoder(tgt.cpu(), mem3.cpu(), sd, 1, 16, None)).abs().max()) < 6e-2
+
+
+def test_timed_checkpoints_and_resume(tmp_path):
+    """Wall-clock saves (models_MMT_v15_4.py:1196-1210: a .pth and a Lightning-layout .ckpt once model_save_interval
+    seconds have passed) and resuming from the .ckpt: weights, AdamW moments, step count and learning rate come back,
+    so the next step of the resumed run equals the next step of the run that wrote the file."""
+    config, cfg = make_config(MODE, 1, drop_out=0.0, model_save_dir=str(tmp_path), model_save_interval=1e9)
+    batch = {k: v.cuda() for k, v in O.synthetic_batch(4, 91, MODE).items()}
+    torch.manual_seed(4)
+    tm = TransformerMultiGPU(config).to("cuda")
+    tm.configure_optimizers()
+    tm.model._engine.step_seed = 99
+    for i in range(2):
+        tm.training_step(batch, i)
+    assert tm.on_batch_end() is None                       # interval not reached: nothing written
+    config.model_save_interval = 0.0
+    pth, ckpt = tm.on_batch_end()
+    assert pth.endswith(".pth") and ckpt.endswith(".ckpt") and "MultimodalTransformer_time_" in pth and "_Loss_" in pth
+    raw = torch.load(ckpt, map_location="cpu", weights_only=True)
+    assert raw["global_step"] == 2 and all(k.startswith("model.") for k in raw["state_dict"])
+    plain = torch.load(pth, map_location="cpu", weights_only=True)
+    assert list(plain.keys()) == [k[len("model."):] for k in raw["state_dict"]]
+    config.model_save_interval = 1e9
+    tm2 = TransformerMultiGPU.load_from_checkpoint(ckpt, config=config, resume_optimizer=True).to("cuda")
+    assert tm2.restore_optimizer() and tm2.optimizer.step_count == 2 and tm2.global_step == 2
+    seed = tm.model._engine.step_seed
+    tm2.model._engine.step_seed = seed
+    a = float(tm.training_step(batch, 2)["loss"])
+    b = float(tm2.training_step(batch, 2)["loss"])
+    assert abs(a - b) < 1e-4
+    sa, sb = tm.model.state_dict(), tm2.model.state_dict()
+    for k in ("decoder.layers.0.linear1.weight", "encoder_cross.layers.0.self_attn.in_proj_weight", "fc_out.weight",
+              "embed_trg.weight"):
+        assert float((sa[k] - sb[k]).abs().max()) < 1e-6, k
