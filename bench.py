@@ -99,6 +99,66 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def decode_bench(args):
+    """Secondary benchmark (BASELINE configuration 4): inference-only beam-search SMILES generation of
+    validate_generate_MMT_v15_4.beam_search for `--batch` molecules x `--beams` beams x gen_len 64 positions on the
+    config_V8 model (6 + 6 layers), encoder memory already resident.  One step = one whole search (replayed from a
+    hipGraph).  Roofline of its dominant kernel, the decoder-stack token step: algorithmic bytes (decoder weights
+    once, every molecule's projected memory keys/values once, every sequence's cached prefix once, the new cache rows
+    and logits written) over the launch durations measured with events on the launch stream."""
+    from multimodalspectraltransformer_amd import synthetic as O
+    from multimodalspectraltransformer_amd import generate as gen
+    from multimodalspectraltransformer_amd.models_MMT import MultimodalTransformer
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    B, W, gen_len = args.batch, args.beams, 64
+    cfg = O.default_config(training_mode=MODE)
+    cfg.update(device=dev, gen_len=gen_len)
+    config = argparse.Namespace(**cfg)
+    torch.manual_seed(1234)
+    model = MultimodalTransformer(config).to(dev).eval()
+    batch = {k: v.to(dev) for k, v in O.synthetic_batch(B, 2000, MODE).items()}
+    batch["src_HSQC_"], batch["src_COSY_"] = batch["src_HSQC"], batch["src_COSY"]
+    stoi = {"<SOS>": 3, "<EOS>": 2}
+    memory, mask, *_ = gen.run_model(model, batch, config)
+    # per-launch timing of the token step in plain-launch mode
+    os.environ["MMST_DECODE_GRAPH"] = "0"
+    gen.beam_search(model, stoi, memory, mask, config, W)
+    gen.STEP_EVENTS = []
+    gen.beam_search(model, stoi, memory, mask, config, W)
+    torch.cuda.synchronize()
+    durs = [a.elapsed_time(b) * 1e-3 for a, b in gen.STEP_EVENTS]
+    gen.STEP_EVENTS = None
+    os.environ["MMST_DECODE_GRAPH"] = "1"
+    nl, Lm, D, FF = model.num_decoder_layers, memory.shape[0], 128, 2048
+    weights = nl * 2 * (3 * D * D + D * D + D * D + D * D + 2 * D * FF) + 2 * 64 * D
+    per_pos = [weights + nl * (B * Lm * 2 * D * 2 + B * W * (pos + 1) * 2 * D * 2 + B * W * 3 * D * 2) + B * W * 64 * 4
+               for pos in range(gen_len)]
+    for i in range(args.warmup):
+        gen.beam_search(model, stoi, memory, mask, config, W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        beams = gen.beam_search(model, stoi, memory, mask, config, W)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not durs:   # the host-ranked search (MMST_BEAM_HOST=1) has no per-launch timing
+        durs = [float("nan")]
+    a = sum(per_pos) / sum(durs) / 1e9
+    res = {"metric": "molecules/sec beam-search SMILES decode", "value": B * args.steps / dt, "unit": "molecules/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"beam search, {B} molecules x {W} beams x {gen_len} positions, {MODE}, config_V8 "
+                                  f"architecture (6+6 layers), KV-cached, bookkeeping on the device, hipGraph replay",
+                      "global_batch": B, "parallelism": "dp1"},
+           "tokens_per_s": B * W * gen_len * args.steps / dt,
+           "roofline": {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
+                        "traffic": pmc_traffic("decode_stack_kernel"),
+                        "algorithmic_bytes_per_launch": sum(per_pos) / gen_len, "kernel": f"decode_stack_kernel<{W}>",
+                        "launches": len(durs), "avg_us": 1e6 * sum(durs) / len(durs)}}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +168,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tap", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--gen", action="store_true", help="also run the in-training greedy generation (secondary metric)")
+    ap.add_argument("--decode", action="store_true", help="secondary benchmark: beam-search decode instead of training")
+    ap.add_argument("--beams", type=int, default=3)
     args = ap.parse_args()
+    if args.decode:
+        if args.batch == 64 and "--batch" not in sys.argv:
+            args.batch = 256
+        return decode_bench(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))

@@ -185,9 +185,38 @@ typedef struct {
   float temperature; int V;
   int B, pos, cap, L;
   int kv_group;                /* >= 1: sequences b*kv_group .. (b+1)*kv_group-1 share row block b of kvc and mem_bias
-                                  (the beams of one molecule); 0 is read as 1 */
+                                  (the beams of one molecule); 0 is read as 1.  Groups of 2..4 sequences are served
+                                  by ONE workgroup: weights and the molecule's memory keys/values are read once for
+                                  all of them */
+  int rows_per_group;          /* 1: one workgroup per sequence even for kv_group 2..4 (the reference arrangement the
+                                  grouped kernel is tested against); 0: as described under kv_group */
+  const int32_t* hist;         /* optional [B][cap] (kv_group 1..4): self-attention reads the key/value of position
+                                  j < pos of sequence b from the cache of sequence (b / kv_group) * kv_group + hist[b][j],
+                                  so a beam that descends from another beam's prefix needs no copy of that prefix's
+                                  cache rows; position pos is always the sequence's own new row */
 } mmst_dec_stack_step;
 int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, const mmst_dec_stack_step* s, int nhead, void* stream);
+
+/* ---- beam search bookkeeping on the device (validate_generate_MMT_v15_4.py:995-1094) ----
+ * State of W beams for each of B molecules; two such states alternate between steps.  A step reads the logits the
+ * decoder produced for the B*W sequences at position `pos` (mmst_decoder_stack_step with kv_group = W and hist = the
+ * CURRENT state's hist), expands every unfinished beam by its W most probable tokens of softmax(logits) (no
+ * temperature, :1038), carries finished beams over, multiplies scores in double precision (the reference's Python
+ * floats), keeps the first W of a stable descending sort (:1052) and writes the NEXT state plus the tokens the
+ * decoder consumes at position pos + 1. */
+#define MMST_MAX_BEAM 4
+typedef struct {
+  int32_t* seqs;     /* [B][W][cap + 1] token ids incl. <SOS> */
+  float* probs;      /* [B][W][cap] probability of every chosen token */
+  double* scores;    /* [B][W] product of the probabilities */
+  int32_t* lens;     /* [B][W] tokens in seqs (incl. <SOS>) */
+  int32_t* nbeams;   /* [B] beams that exist (1 before the first step, W afterwards) */
+  int32_t* hist;     /* [B*W][cap] see mmst_dec_stack_step.hist */
+} mmst_beam_state;
+/* one beam (<SOS>) per molecule, tok[b*W + w] = sos for every slot */
+int mmst_beam_init(const mmst_beam_state* st, int64_t* tok, int B, int W, int cap, int sos, void* stream);
+int mmst_beam_step(const float* logits, int ld_logits, int V, const mmst_beam_state* cur, const mmst_beam_state* next,
+                   int64_t* tok, int B, int W, int cap, int pos, int eos, void* stream);
 
 typedef struct {
   const void* dz3; const void* dzd3;
@@ -292,6 +321,11 @@ int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float 
 /* torch.optim.AdamW step (:1213-1214) on flat fp32 buffers + refresh of the bf16 weight copy. */
 int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_bf16, long n, float lr, float beta1,
                float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same update over n_ranges (<= 16) element ranges [lo[i], hi[i]) of the flat buffers in one launch (offsets and
+ * lengths multiples of 4); zero_grad != 0 leaves the gradient of those ranges zeroed for the next step. */
+int mmst_adamw_ranges(float* param, float* grad, float* m, float* v, void* param_bf16, int n_ranges, const long* lo,
+                      const long* hi, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float grad_scale, int zero_grad, void* stream);
 /* fp32 -> bf16 copy of a [rows][cols] matrix into a [rows][ld_out] one (padded weight copies). */
 int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, void* stream);
 
@@ -384,7 +418,8 @@ typedef struct {
   const int64_t* trg; int trg_ld;     /* trg_enc_SMI [B][trg_ld] batch-first; input = columns 0..T-1, targets 1..T */
   uint32_t step_seed;                 /* dropout stream of this step */
   float drop_layers, drop_embed;      /* 0.1 / config.drop_out in train mode, 0 in eval mode */
-  int zero_grads;                     /* nonzero: clear the active ranges of G first */
+  int zero_grads;                     /* nonzero: clear the active ranges of G first (not needed after a step whose
+                                         optimizer ran inside mmst_train_step: it leaves them zeroed) */
   float loss_grad_scale;
   int adam_step;                      /* >= 1: AdamW with this step count after backward; 0: leave the weights alone */
   float lr, beta1, beta2, eps, weight_decay, grad_scale;

@@ -170,7 +170,7 @@ class DecStackStep(C.Structure):
         "mem_bias", "w_out", "b_out", "logits") + [("ld_logits", C.c_int), ("n_out", C.c_int)] + _ptrs(
         "next_tok", "next_prob") + [("temperature", C.c_float), ("V", C.c_int),
                                     ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int),
-                                    ("kv_group", C.c_int)]
+                                    ("kv_group", C.c_int), ("rows_per_group", C.c_int), ("hist", C.c_void_p)]
 
 
 class DecBwd(C.Structure):
@@ -230,3 +230,10 @@ class StepArgs(C.Structure):
                  ("adam_step", C.c_int)] +
                 [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")] +
                 [("on_segment", SEGMENT_CALLBACK), ("user", C.c_void_p)])
+
+
+class BeamState(C.Structure):
+    _fields_ = _ptrs("seqs", "probs", "scores", "lens", "nbeams", "hist")
+
+
+MAX_BEAM = 4

@@ -39,9 +39,9 @@ extern thread_local hipEvent_t mmst_armed_stop_event;   // defined in gemm.hip
 // Host-side helpers shared between the entry-point files.
 // `to` (if not null) waits for everything enqueued on `from` so far; events come from a per-device ring (layers.hip).
 int mmst_stream_fork(hipStream_t from, hipStream_t to);
-// target-embedding launchers with explicit token strides (misc.hip)
+// target-embedding launchers with explicit token strides (misc.hip); `clear`: optional fp32 slot set to zero
 int launch_trg_embed_fwd(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos, void* out,
-                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream);
+                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream, float* clear);
 int launch_trg_embed_bwd(const int64_t* tok, int tok_ld, int tok_bs, const void* dout, float* d_embed, float* d_pos,
                          int B, int T, int V, float drop_p, uint32_t seed, hipStream_t stream);
 

@@ -28,14 +28,21 @@ struct StackArgs {
   int n_layers;
 };
 
+// R = sequences per workgroup.  R > 1: the workgroup owns the R sequences (beams) of ONE molecule; every weight row
+// it streams serves R rows, and the molecule's projected memory keys/values are read once for all of them.
+// Every row that feeds a projection is bf16-exact, so it is kept in LDS as bf16: a lane fetches its slice of a row
+// with one or two 16-byte LDS reads where it needs it instead of holding all R rows in registers across the
+// weight loop (registers are what limits the number of weight loads in flight).
+template <int R>
 struct Smem {
-  float x[D];          // input row of the current layer
-  float qkv[3 * D];    // Q|K|V of the new position
-  float attn[D];
-  float x1[D];
-  float qc[D];
-  float x2[D];
-  float h[FF];
+  float x[R][D];          // input rows of the current layer (fp32 copy for the residual)
+  float qkv[R][3 * D];    // Q|K|V of the new position
+  float x1[R][D];
+  float qc[R][D];
+  float x2[R][D];
+  __attribute__((aligned(16))) bf16 vx[R][D];      // packed copies of the rows that enter the next projection
+  __attribute__((aligned(16))) bf16 vattn[R][D];
+  __attribute__((aligned(16))) bf16 vh[R][FF];
   float part[NWAVE][NH][HD + 2];   // per-wave softmax partials: m, l, acc[8]
   float red[2][NWAVE];
 };
@@ -59,22 +66,25 @@ __device__ __forceinline__ float dot8p(const bf16x8& w, const bf16x2 (&v)[4], fl
   return acc;
 }
 
-// out[n] = bias[n] + sum_k W[n][k] v[k] for K = 128, n < rows <= N (N a multiple of NT/8 or smaller than it): eight lanes
-// per output row (16 contiguous weights each), NT/8 rows per pass of the workgroup, the loads of U passes in
-// flight before the first one is consumed (a dependent L2 round trip per pass would dominate otherwise).
-// `emit(n, value)` is called by one lane per row.
-template <int N, int U, typename F>
-__device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const float* __restrict__ bias, const float* v, int tid,
-                                          F emit, int rows = N) {
+__device__ __forceinline__ float dot8b(const bf16x8& w, const bf16x8& v, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(v, v, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(v, v, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(v, v, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(v, v, 6, 7), acc, false);
+  return acc;
+}
+
+// out[r][n] = bias[n] + sum_k W[n][k] v[r][k] for K = 128, n < rows <= N (N a multiple of NT/8 or smaller than it), R
+// input rows v + r*vstride (bf16 in LDS): eight lanes per output row (16 contiguous weights each, loaded ONCE for the
+// R rows), NT/8 output rows per pass of the workgroup, the loads of U passes in flight before the first one is
+// consumed (a dependent L2 round trip per pass would dominate otherwise).  `emit(r, n, value)` is called by one lane
+// per output row.
+template <int R, int N, int U, typename F>
+__device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const float* __restrict__ bias, const bf16* v,
+                                          int vstride, int tid, F emit, int rows = N) {
   constexpr int RP = NT / 8, PASSES = (N + RP - 1) / RP;
   static_assert(PASSES % U == 0, "U must divide the number of passes");
   const int sub = tid & 7, r0 = tid >> 3;
-  bf16x2 va[4], vb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    va[j] = pack2(v[sub * 16 + 2 * j], v[sub * 16 + 2 * j + 1]);
-    vb[j] = pack2(v[sub * 16 + 8 + 2 * j], v[sub * 16 + 8 + 2 * j + 1]);
-  }
 #pragma unroll 1
   for (int p0 = 0; p0 < PASSES; p0 += U) {
     bf16x8 a[U], b[U];
@@ -85,29 +95,30 @@ __device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const floa
       b[u] = *reinterpret_cast<const bf16x8*>(W + (size_t)n * D + sub * 16 + 8);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int n = (p0 + u) * RP + r0;
-      float s = dot8p(a[u], va, 0.f) + dot8p(b[u], vb, 0.f);
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      if (sub == 0 && n < rows) emit(n, s + (bias ? bias[n] : 0.f));
+    for (int r = 0; r < R; ++r) {
+      const bf16x8 va = *reinterpret_cast<const bf16x8*>(v + r * vstride + sub * 16);
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(v + r * vstride + sub * 16 + 8);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = (p0 + u) * RP + r0;
+        float s = dot8b(a[u], va, 0.f) + dot8b(b[u], vb, 0.f);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0 && n < rows) emit(r, n, s + (bias ? bias[n] : 0.f));
+      }
     }
   }
 }
 
-// out[n] = bias[n] + sum_k W[n][k] v[k] for K = 2048, N = 128: a wave per output row, U rows (4 U loads) in flight
-template <int U, typename F>
-__device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const float* __restrict__ bias, const float* v, int tid,
-                                           F emit) {
+// out[r][n] = bias[n] + sum_k W[n][k] v[r][k] for K = 2048, N = 128: a wave per output row, U rows (4 U loads) in
+// flight, every weight row used for the R input rows (bf16 in LDS)
+template <int R, int U, typename F>
+__device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const float* __restrict__ bias, const bf16* v,
+                                           int vstride, int tid, F emit) {
   constexpr int ROWS = D / NWAVE;   // rows per wave
   static_assert(ROWS % U == 0, "U must divide the rows per wave");
   const int lane = tid & 63, wave = tid >> 6;
-  bf16x2 vin[4][4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vin[c][j] = pack2(v[c * 512 + lane * 8 + 2 * j], v[c * 512 + lane * 8 + 2 * j + 1]);
 #pragma unroll 1
   for (int i0 = 0; i0 < ROWS; i0 += U) {
     bf16x8 a[U][4];
@@ -117,86 +128,52 @@ __device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const flo
       for (int c = 0; c < 4; ++c)
         a[u][c] = *reinterpret_cast<const bf16x8*>(W + (size_t)(wave * ROWS + i0 + u) * FF + c * 512 + lane * 8);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float s = (dot8p(a[u][0], vin[0], 0.f) + dot8p(a[u][1], vin[1], 0.f)) +
-                (dot8p(a[u][2], vin[2], 0.f) + dot8p(a[u][3], vin[3], 0.f));
-      s = wave_sum(s);
-      const int n = wave * ROWS + i0 + u;
-      if (lane == 0) emit(n, s + (bias ? bias[n] : 0.f));
+    for (int r = 0; r < R; ++r) {
+      bf16x8 vin[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vin[c] = *reinterpret_cast<const bf16x8*>(v + r * vstride + c * 512 + lane * 8);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = wave * ROWS + i0 + u;
+        float s = (dot8b(a[u][0], vin[0], 0.f) + dot8b(a[u][1], vin[1], 0.f)) +
+                  (dot8b(a[u][2], vin[2], 0.f) + dot8b(a[u][3], vin[3], 0.f));
+        s = wave_sum(s);
+        if (lane == 0) emit(r, n, s + (bias ? bias[n] : 0.f));
+      }
     }
   }
 }
 
-// z[0..128) (one value per thread tid < 128) -> LayerNorm -> out[] as bf16-rounded floats
-__device__ __forceinline__ void layernorm_row(Smem& sm, float z, const float* gamma, const float* beta, float* out, int tid) {
+// R rows z[r][0..128) (thread tid < R*128 holds element tid & 127 of row tid >> 7, i.e. waves 2r and 2r+1 hold row r)
+// -> LayerNorm -> out[r][] as bf16-rounded floats
+template <int R>
+__device__ __forceinline__ void layernorm_rows(Smem<R>& sm, float z, const float* gamma, const float* beta, float (*out)[D],
+                                               bf16 (*packed)[D], int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  const bool own = tid < D;
+  const bool own = tid < R * D;
+  const int r = own ? (tid >> 7) : 0, c = tid & (D - 1);
   float s = wave_sum(own ? z : 0.f);
   if (lane == 0) sm.red[0][wave] = s;
   lds_barrier();
-  const float mean = (sm.red[0][0] + sm.red[0][1]) * (1.0f / D);
+  const float mean = (sm.red[0][2 * r] + sm.red[0][2 * r + 1]) * (1.0f / D);
   const float d = own ? z - mean : 0.f;
   float vs = wave_sum(d * d);
   if (lane == 0) sm.red[1][wave] = vs;
   lds_barrier();
-  const float rstd = rsqrtf((sm.red[1][0] + sm.red[1][1]) * (1.0f / D) + 1e-5f);
-  if (own) out[tid] = rbf(d * rstd * gamma[tid] + beta[tid]);
+  const float rstd = rsqrtf((sm.red[1][2 * r] + sm.red[1][2 * r + 1]) * (1.0f / D) + 1e-5f);
+  if (own) {
+    const bf16 y = (bf16)(d * rstd * gamma[c] + beta[c]);
+    out[r][c] = (float)y;
+    packed[r][c] = y;
+  }
   lds_barrier();
 }
 
-// Attention of one query row (sm q[128], 16 heads x 8) over `nkeys` keys: K row of key j at kbase + j*ld, V at
-// vbase + j*ld (bf16, 128 wide).  Lane = (key slot, head): 16 lanes read one key's 256-byte row, a wave covers
-// 4 keys per step, the workgroup 32.  If last_k != nullptr, key nkeys-1 is read from LDS instead (the row this
-// workgroup has just produced).  Result -> sm.attn (bf16-rounded).
-__device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kbase, const bf16* vbase, size_t ld, int nkeys,
-                                       const float* kbias, const float* last_k, const float* last_v, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const int hh = lane & 15, slot = wave * 4 + (lane >> 4);
-  const float scale2 = rsqrtf((float)HD) * LOG2E;
-  bf16x2 qv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) qv[j] = pack2(q[hh * HD + 2 * j], q[hh * HD + 2 * j + 1]);
-  float m = NEG_BIG, l = 0.f, acc[HD];
-#pragma unroll
-  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-  constexpr int U = 4, STEP = 4 * NWAVE;
-#pragma unroll 1
-  for (int k0 = slot; k0 < nkeys; k0 += U * STEP) {
-    bf16x8 kt[U], vt[U];
-    float sc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = min(k0 + u * STEP, nkeys - 1);
-      kt[u] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)key * ld + hh * HD);
-      vt[u] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)key * ld + hh * HD);
-      sc[u] = kbias ? kbias[key] * LOG2E : 0.f;
-    }
-    // scores of the batch, one rescale of the running sums per batch
-    float mb = m;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = k0 + u * STEP;
-      if (last_k && key == nkeys - 1) {   // the row this workgroup has just produced: not yet visible in memory
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { kt[u][d] = (bf16)last_k[hh * HD + d]; vt[u][d] = (bf16)last_v[hh * HD + d]; }
-      }
-      sc[u] = key < nkeys ? dot8p(kt[u], qv, 0.f) * scale2 + sc[u] : NEG_BIG;
-      mb = fmaxf(mb, sc[u]);
-    }
-    const float alpha = __builtin_amdgcn_exp2f(m - mb);
-    m = mb;
-    l *= alpha;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) acc[d] *= alpha;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float p = (k0 + u * STEP) < nkeys ? __builtin_amdgcn_exp2f(sc[u] - mb) : 0.f;
-      l += p;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] += p * (float)vt[u][d];
-    }
-  }
-  // merge the 4 key slots of the wave (lanes with equal head), then the waves through LDS
+// merge of the per-lane online-softmax states (m, l, acc[8]) of one query row: the 4 key slots of a wave (lanes with
+// equal head), then the waves through LDS; result -> out[0..128) (bf16-rounded)
+template <int R>
+__device__ __forceinline__ void merge_softmax(Smem<R>& sm, float m, float l, float (&acc)[HD], bf16* out, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, hh = lane & 15;
   float M = fmaxf(m, __shfl_xor(m, 16));
   M = fmaxf(M, __shfl_xor(M, 32));
   const float f = __builtin_amdgcn_exp2f(m - M);
@@ -228,89 +205,180 @@ __device__ __forceinline__ void attend(Smem& sm, const float* q, const bf16* kba
       L += sm.part[w][h2][1] * g;
       A += sm.part[w][h2][2 + d] * g;
     }
-    sm.attn[tid] = rbf(A * (L > 0.f ? 1.0f / L : 0.f));
+    out[tid] = (bf16)(A * (L > 0.f ? 1.0f / L : 0.f));
   }
   lds_barrier();
 }
 
-__global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) {
-  __shared__ Smem sm;
-  const mmst_dec_stack_step& s = args.s;
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int pos = s.pos;
-  // input row: given, or embedding of the token + positional row
-  if (tid < D) {
-    float v;
-    if (s.tok) {
-      const int64_t tk = s.tok[b];
-      v = rbf(s.embed[(size_t)tk * D + tid] + s.pos_row[tid]);
-    } else {
-      v = (float)((const bf16*)s.x)[(size_t)b * D + tid];
+// Attention of Q query rows (q + r*qstride, 16 heads x 8) over the SAME `nkeys` keys: K row of key j at kbase + j*ld, V
+// at vbase + j*ld (bf16, 128 wide) -- unless `slot_of` is given: then key j lives in the cache of sequence slot_of[j] of
+// the molecule, kbase + (slot_of[j]*cap + j)*ld (a beam's history points into the caches of the beams it descends
+// from).  Lane = (key slot, head): 16 lanes read one key's 256-byte row, a wave covers 4 keys per step, the
+// workgroup 64.  If last_k != nullptr (Q == 1 only), key nkeys-1 is read from LDS instead (the row this workgroup
+// has just produced).  Results -> out + r*D (bf16-rounded).
+template <int R, int Q>
+__device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
+                                       int nkeys, const float* kbias, const float* last_k, const float* last_v,
+                                       const int32_t* slot_of, int cap, bf16* out, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hh = lane & 15, slot = wave * 4 + (lane >> 4);
+  const float scale2 = rsqrtf((float)HD) * LOG2E;
+  bf16x2 qv[Q][4];
+#pragma unroll
+  for (int r = 0; r < Q; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qv[r][j] = pack2(q[r * qstride + hh * HD + 2 * j], q[r * qstride + hh * HD + 2 * j + 1]);
+  float m[Q], l[Q], acc[Q][HD];
+#pragma unroll
+  for (int r = 0; r < Q; ++r) {
+    m[r] = NEG_BIG;
+    l[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[r][d] = 0.f;
+  }
+  constexpr int U = Q > 2 ? 2 : 4, STEP = 4 * NWAVE;
+#pragma unroll 1
+  for (int k0 = slot; k0 < nkeys; k0 += U * STEP) {
+    bf16x8 kt[U], vt[U];
+    float kb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = min(k0 + u * STEP, nkeys - 1);
+      const size_t row = slot_of ? (size_t)slot_of[key] * cap + key : (size_t)key;
+      kt[u] = *reinterpret_cast<const bf16x8*>(kbase + row * ld + hh * HD);
+      vt[u] = *reinterpret_cast<const bf16x8*>(vbase + row * ld + hh * HD);
+      kb[u] = kbias ? kbias[key] * LOG2E : 0.f;
     }
-    sm.x[tid] = v;
+    if (Q == 1 && last_k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (k0 + u * STEP == nkeys - 1) {   // the row this workgroup has just produced: not yet visible in memory
+#pragma unroll
+          for (int d = 0; d < HD; ++d) { kt[u][d] = (bf16)last_k[hh * HD + d]; vt[u][d] = (bf16)last_v[hh * HD + d]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < Q; ++r) {
+      // scores of the batch, one rescale of the running sums per batch
+      float sc[U];
+      float mb = m[r];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        sc[u] = (k0 + u * STEP) < nkeys ? dot8p(kt[u], qv[r], 0.f) * scale2 + kb[u] : NEG_BIG;
+        mb = fmaxf(mb, sc[u]);
+      }
+      const float alpha = __builtin_amdgcn_exp2f(m[r] - mb);
+      m[r] = mb;
+      l[r] *= alpha;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[r][d] *= alpha;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float p = (k0 + u * STEP) < nkeys ? __builtin_amdgcn_exp2f(sc[u] - mb) : 0.f;
+        l[r] += p;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[r][d] += p * (float)vt[u][d];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < Q; ++r) merge_softmax<R>(sm, m[r], l[r], acc[r], out + r * D, tid);
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) {
+  __shared__ Smem<R> sm;
+  const mmst_dec_stack_step& s = args.s;
+  const int tid = threadIdx.x, g = blockIdx.x;
+  const int b0 = g * R;               // first sequence of this workgroup
+  const int pos = s.pos;
+  // input rows: given, or embedding of the token + positional row
+  if (tid < R * D) {
+    const int r = tid >> 7, c = tid & (D - 1);
+    bf16 v;
+    if (s.tok) {
+      const int64_t tk = s.tok[b0 + r];
+      v = (bf16)(s.embed[(size_t)tk * D + c] + s.pos_row[c]);
+    } else {
+      v = ((const bf16*)s.x)[(size_t)(b0 + r) * D + c];
+    }
+    sm.x[r][c] = (float)v;
+    sm.vx[r][c] = v;
   }
   lds_barrier();
-  const int bm = b / s.kv_group;   // row block of the encoder memory this sequence reads
+  const int bm = R > 1 ? g : b0 / s.kv_group;   // row block of the encoder memory these sequences read
   const float* mbias = s.mem_bias ? s.mem_bias + (size_t)bm * s.L : nullptr;
+  // loads in flight per lane in the two big weight streams: as many as the register budget of 128 allows
+  constexpr int U1 = 8, U2 = 4;
   for (int l = 0; l < args.n_layers; ++l) {
     const mmst_dec_params& p = args.p[l];
-    bf16* cache = (bf16*)s.qkv_cache[l] + (size_t)b * s.cap * 3 * D;
-    // 1. Q|K|V of the new position, appended to the cache
-    bf16* crow = cache + (size_t)pos * 3 * D;
-    gemv_k128<3 * D, 3>((const bf16*)p.w_qkv, p.b_qkv, sm.x, tid, [&](int n, float v) {
-      const bf16 r = (bf16)v;
-      sm.qkv[n] = (float)r;
-      crow[n] = r;
+    bf16* cache = (bf16*)s.qkv_cache[l] + (size_t)b0 * s.cap * 3 * D;   // caches of this workgroup's sequences
+    // 1. Q|K|V of the new position, appended to each sequence's own cache
+    gemv_k128<R, 3 * D, 3>((const bf16*)p.w_qkv, p.b_qkv, &sm.vx[0][0], D, tid, [&](int r, int n, float v) {
+      const bf16 q = (bf16)v;
+      sm.qkv[r][n] = (float)q;
+      cache[((size_t)r * s.cap + pos) * 3 * D + n] = q;
     });
     lds_barrier();
-    // 2. self-attention over positions 0..pos (every cached key is visible)
-    attend(sm, sm.qkv, cache + D, cache + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv + D, sm.qkv + 2 * D, tid);
+    // 2. self-attention over positions 0..pos (every cached key is visible).  With a history table the key of position
+    //    j is read from the cache of the sequence that produced it (slot hist[b][j] of this molecule); position `pos`
+    //    itself is the row just computed.
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
+      const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
+      attend<R, 1>(sm, sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist,
+                   s.cap, sm.vattn[r], tid);
+    }
     // 3. out_proj + residual + norm1
-    float z = 0.f;
-    gemv_k128<D, 1>((const bf16*)p.w_o, p.b_o, sm.attn, tid, [&](int n, float v) { sm.qc[n] = v + sm.x[n]; });
+    gemv_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], D, tid,
+                       [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x[r][n]; });
     lds_barrier();
-    z = tid < D ? sm.qc[tid] : 0.f;
-    layernorm_row(sm, z, p.g1, p.be1, sm.x1, tid);
-    // 4. cross-attention query
-    gemv_k128<D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, sm.x1, tid, [&](int n, float v) { sm.qc[n] = rbf(v); });
+    float z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
+    layernorm_rows<R>(sm, z, p.g1, p.be1, sm.x1, sm.vx, tid);
+    // 4. cross-attention queries
+    gemv_k128<R, D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, &sm.vx[0][0], D, tid,
+                       [&](int r, int n, float v) { sm.qc[r][n] = rbf(v); });
     lds_barrier();
-    // 5. cross-attention over the projected memory
+    // 5. cross-attention over the projected memory: one pass over the molecule's keys/values for all R queries
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
-    attend(sm, sm.qc, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, tid);
+    attend<R, R>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0, &sm.vattn[0][0], tid);
     // 6. out_proj + residual + norm2
-    gemv_k128<D, 1>((const bf16*)p.w_co, p.b_co, sm.attn, tid, [&](int n, float v) { sm.qc[n] = v + sm.x1[n]; });
+    gemv_k128<R, D, 1>((const bf16*)p.w_co, p.b_co, &sm.vattn[0][0], D, tid,
+                       [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x1[r][n]; });
     lds_barrier();
-    z = tid < D ? sm.qc[tid] : 0.f;
-    layernorm_row(sm, z, p.g2, p.be2, sm.x2, tid);
+    z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
+    layernorm_rows<R>(sm, z, p.g2, p.be2, sm.x2, sm.vx, tid);
     // 7. feed-forward block + norm3
-    gemv_k128<FF, 8>((const bf16*)p.w_1, p.b_1, sm.x2, tid, [&](int n, float v) { sm.h[n] = rbf(fmaxf(v, 0.f)); });
+    gemv_k128<R, FF, U1>((const bf16*)p.w_1, p.b_1, &sm.vx[0][0], D, tid,
+                         [&](int r, int n, float v) { sm.vh[r][n] = (bf16)fmaxf(v, 0.f); });
     lds_barrier();
-    gemv_k2048<4>((const bf16*)p.w_2, p.b_2, sm.h, tid, [&](int n, float v) { sm.qc[n] = v + sm.x2[n]; });
+    gemv_k2048<R, U2>((const bf16*)p.w_2, p.b_2, &sm.vh[0][0], FF, tid,
+                      [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x2[r][n]; });
     lds_barrier();
-    z = tid < D ? sm.qc[tid] : 0.f;
-    layernorm_row(sm, z, p.g3, p.be3, sm.x, tid);
+    z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
+    layernorm_rows<R>(sm, z, p.g3, p.be3, sm.x, sm.vx, tid);
   }
-  if (s.y && tid < D) ((bf16*)s.y)[(size_t)b * D + tid] = (bf16)sm.x[tid];
+  if (s.y && tid < R * D) ((bf16*)s.y)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
   if (!s.logits) return;
   // vocabulary projection (weight rows beyond the vocabulary are zero padding of the caller's matrix)
-  float* lg = s.logits + (size_t)b * s.ld_logits;
-  gemv_k128<64, 1>((const bf16*)s.w_out, s.b_out, sm.x, tid, [&](int n, float v) {
-    sm.qc[n] = v;
-    lg[n] = v;
+  gemv_k128<R, 64, 1>((const bf16*)s.w_out, s.b_out, &sm.vx[0][0], D, tid, [&](int r, int n, float v) {
+    sm.qc[r][n] = v;
+    s.logits[(size_t)(b0 + r) * s.ld_logits + n] = v;
   }, s.n_out);
   if (!s.next_tok) return;
   lds_barrier();
-  if (tid < 64) {   // softmax(logits / temperature), first index of the maximum
-    const int lane = tid;
-    const float x = lane < s.V ? sm.qc[lane] / s.temperature : -INFINITY;
+  if (tid < 64 * R) {   // wave r: softmax(logits / temperature) of row r, first index of the maximum
+    const int lane = tid & 63, r = tid >> 6;
+    const float x = lane < s.V ? sm.qc[r][lane] / s.temperature : -INFINITY;
     const float mx = wave_max(x);
     const float e = lane < s.V ? __expf(x - mx) : 0.f;
     const float se = wave_sum(e);
     const unsigned long long mk = __ballot(x == mx);
     const int arg = __ffsll((long long)mk) - 1;
     if (lane == arg) {
-      s.next_tok[b] = arg;
-      if (s.next_prob) s.next_prob[b] = e / se;
+      s.next_tok[b0 + r] = arg;
+      if (s.next_prob) s.next_prob[b0 + r] = e / se;
     }
   }
 }
@@ -324,6 +392,7 @@ extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, c
   if (!p || !s || nhead != NH || n_layers < 1 || n_layers > MMST_MAX_DEC_LAYERS) return MMST_ERR_ARG;
   if (s->B < 1 || s->pos < 0 || s->pos >= s->cap || s->L < 1 || s->kv_group < 0) return MMST_ERR_ARG;
   if (s->kv_group > 1 && s->B % s->kv_group != 0) return MMST_ERR_ARG;
+  if (s->hist && (s->kv_group < 1 || s->kv_group > 4)) return MMST_ERR_ARG;   // history tables need the grouped kernel
   if (!s->tok && !s->x) return MMST_ERR_ARG;
   if (s->tok && (!s->embed || !s->pos_row)) return MMST_ERR_ARG;
   if (!s->y && !s->logits) return MMST_ERR_ARG;
@@ -338,7 +407,15 @@ extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, c
   a.s = *s;
   if (a.s.kv_group < 1) a.s.kv_group = 1;
   a.n_layers = n_layers;
-  hipLaunchKernelGGL(decode_stack_kernel, dim3(s->B), dim3(NT), 0, (hipStream_t)stream, a);
+  // the beams of a molecule (kv_group of 2..4 sequences) share one workgroup; otherwise one workgroup per sequence
+  const int R = (a.s.kv_group >= 2 && a.s.kv_group <= 4 && a.s.rows_per_group != 1) ? a.s.kv_group : 1;
+  if (a.s.hist && R != a.s.kv_group) return MMST_ERR_ARG;
+  switch (R) {
+    case 1: hipLaunchKernelGGL(decode_stack_kernel<1>, dim3(s->B), dim3(NT), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(decode_stack_kernel<2>, dim3(s->B / 2), dim3(NT), 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL(decode_stack_kernel<3>, dim3(s->B / 3), dim3(NT), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(decode_stack_kernel<4>, dim3(s->B / 4), dim3(NT), 0, (hipStream_t)stream, a); break;
+  }
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

@@ -178,8 +178,9 @@ __global__ void seq_mean_kernel(const bf16* mem, bf16* out, int L) {
 
 // token of (position t, sequence b) = tok[t * tok_ld + b * tok_bs]: (T, B) row-major is (B, 1), batch-first (B, 64) is (1, 64)
 __global__ void trg_embed_fwd_kernel(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos,
-                                     bf16* out, int B, int T, float drop_p, uint32_t seed) {
+                                     bf16* out, int B, int T, float drop_p, uint32_t seed, float* clear) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid == 0 && clear) *clear = 0.f;   // the step's loss accumulator, long before the loss kernel adds to it
   const int row = gid >> 4, c0 = (gid & 15) * 8;
   if (row >= B * T) return;
   const int b = row / T, t = row % T;
@@ -361,6 +362,46 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// AdamW over several [lo, hi) ranges of the flat buffers in ONE launch; optionally leaves the gradient zeroed for
+// the next step (saves a separate pass over the gradient buffer).  Ranges are multiples of 4 elements at offsets that
+// are multiples of 4 (the arena aligns every tensor to 64 elements).
+#define ADAMW_MAX_RANGES 16
+struct AdamRanges {
+  int n;
+  long lo[ADAMW_MAX_RANGES];
+  long cum[ADAMW_MAX_RANGES + 1];   // cum[i] = number of 4-element groups before range i
+};
+__global__ void adamw_ranges_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, bf16* __restrict__ pb, const AdamRanges R, float lr, float b1,
+                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, int zero_g) {
+  const long total = R.cum[R.n];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    int r = 0;
+    while (r + 1 < R.n && q >= R.cum[r + 1]) ++r;
+    const long i = R.lo[r] + (q - R.cum[r]) * 4;
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+    bf16x4 ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gg[e] * gscale;
+      float pe = pp[e] * (1.f - lr * wd);
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pe -= (lr / bc1) * (mm[e] / denom);
+      pp[e] = pe;
+      ob[e] = (bf16)pe;
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pp;
+    *reinterpret_cast<f32x4*>(m + i) = mm;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+    if (pb) *reinterpret_cast<bf16x4*>(pb + i) = ob;
+    if (zero_g) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 __global__ void cast_kernel(const float* src, bf16* dst, int rows, int cols, int ld_out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * cols) return;
@@ -410,11 +451,11 @@ int fill_embed_args(EmbedArgs& A, int n, const mmst_embed_group* g, const mmst_e
 
 // target-embedding launchers with a token stride per position and per sequence (see trg_embed_fwd_kernel)
 int launch_trg_embed_fwd(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos, void* out,
-                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream) {
+                         int B, int T, float drop_p, uint32_t seed, hipStream_t stream, float* clear) {
   if (!tok || !embed || !pos || !out || B < 1 || T < 1) return MMST_ERR_ARG;
   const int threads = B * T * 16;
   hipLaunchKernelGGL(trg_embed_fwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, tok, tok_ld, tok_bs,
-                     embed, pos, (bf16*)out, B, T, drop_p, seed);
+                     embed, pos, (bf16*)out, B, T, drop_p, seed, clear);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
@@ -464,7 +505,7 @@ int mmst_seq_mean(const void* mem, void* out, int B, int L, void* stream) {
 
 int mmst_trg_embed_fwd(const int64_t* tok, int tok_ld, const float* embed, const float* pos, void* out, int B, int T,
                        float drop_p, uint32_t seed, void* stream) {
-  return launch_trg_embed_fwd(tok, tok_ld, 1, embed, pos, out, B, T, drop_p, seed, (hipStream_t)stream);
+  return launch_trg_embed_fwd(tok, tok_ld, 1, embed, pos, out, B, T, drop_p, seed, (hipStream_t)stream, nullptr);
 }
 
 int mmst_trg_embed_bwd(const int64_t* tok, int tok_ld, const void* dout, float* d_embed, float* d_pos, int B, int T,
@@ -531,6 +572,29 @@ int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
                      (bf16*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_adamw_ranges(float* param, float* grad, float* m, float* v, void* param_bf16, int n_ranges, const long* lo,
+                      const long* hi, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float grad_scale, int zero_grad, void* stream) {
+  if (!param || !grad || !m || !v || !lo || !hi || n_ranges < 1 || n_ranges > ADAMW_MAX_RANGES || step < 1)
+    return MMST_ERR_ARG;
+  AdamRanges R;
+  R.n = n_ranges;
+  R.cum[0] = 0;
+  for (int i = 0; i < n_ranges; ++i) {
+    if (lo[i] < 0 || hi[i] <= lo[i] || (lo[i] & 3) || ((hi[i] - lo[i]) & 3)) return MMST_ERR_ARG;
+    R.lo[i] = lo[i];
+    R.cum[i + 1] = R.cum[i] + (hi[i] - lo[i]) / 4;
+  }
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  long blocks = (R.cum[n_ranges] + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     (bf16*)param_bf16, R, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, zero_grad);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

@@ -92,7 +92,7 @@ int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed
   }
   // decoder on the batch-first token matrix: input token of (t, b) = trg[b][t]
   RUN(launch_trg_embed_fwd(ar->trg, 1, ar->trg_ld, pl->embed_trg, pl->pe_trg, pl->trg_emb, B, T, ar->drop_embed,
-                           layer_seed(ar->step_seed, UID_TRG), st));
+                           layer_seed(ar->step_seed, UID_TRG), st, pl->loss));
   for (int l = 0; l < ndl; ++l) {
     mmst_dec_acts a = *pl->dec_a[l];
     a.T = T; a.kv_ready = 0; a.no_causal = 0;
@@ -105,7 +105,6 @@ int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed
     q.Pn = B * T; q.Qn = VPAD; q.K = D; q.flags = GF_OUT_F32;
     RUN(one_gemm(q, EPI_BIAS, false, false, st));
   }
-  if (hipMemsetAsync(pl->loss, 0, sizeof(float), st) != hipSuccess) return MMST_ERR_LAUNCH;
   return mmst_ce_loss(pl->logits, VPAD, pl->vocab, ar->trg, ar->trg_ld, B, T, pl->loss, pl->dlogits,
                       ar->loss_grad_scale, st);
 }
@@ -212,11 +211,9 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
 
 int optimizer(const mmst_step_plan* pl, const mmst_step_args* ar, hipStream_t st, hipStream_t wst) {
   if (!pl->M || !pl->V) return MMST_ERR_ARG;
-  for (int i = 0; i < pl->n_ranges; ++i) {
-    const long lo = pl->range_lo[i], nel = pl->range_hi[i] - lo;
-    RUN(mmst_adamw(pl->P + lo, pl->G + lo, pl->M + lo, pl->V + lo, (bf16*)pl->Pb + lo, nel, ar->lr, ar->beta1, ar->beta2,
-                   ar->eps, ar->weight_decay, ar->adam_step, ar->grad_scale, st));
-  }
+  // one launch over every active range; it also leaves the gradient zeroed for the next step
+  RUN(mmst_adamw_ranges(pl->P, pl->G, pl->M, pl->V, pl->Pb, pl->n_ranges, pl->range_lo, pl->range_hi, ar->lr, ar->beta1,
+                        ar->beta2, ar->eps, ar->weight_decay, ar->adam_step, ar->grad_scale, 1, st));
   // the transposed feed-forward weights are read by the backward pass only: refresh them on the second stream,
   // beside the next forward pass (the next backward waits for that stream first)
   RUN(mmst_stream_fork(st, wst));

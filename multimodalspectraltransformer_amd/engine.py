@@ -102,6 +102,7 @@ class Arena:
         self.named = named
         self.use_real_data = bool(getattr(model.config, "use_real_data", False))
         self.shadow_stale = True
+        self.grads_zeroed = False      # True right after a step whose fused optimizer left the active gradients zeroed
         self.weights_serial = 0        # counts rewrites of the bf16 weight copy (caches of projected tensors key on it)
         self.transposed_ready = None   # event after the last refresh of PbT on another stream than the caller's
 
@@ -831,8 +832,10 @@ class Engine:
         pl.mask_is_bool = glob_bool
         pl.encode_serial = getattr(pl, "encode_serial", 0) + 1
         pl._step_keep = (keep, cb)     # inputs stay referenced until the next step has been enqueued
+        self.arena.grads_zeroed = False
         L.check(L.lib().mmst_train_step(C.byref(sp), C.byref(a), C.c_void_p(main.cuda_stream),
                                         C.c_void_p(ws.cuda_stream)), "mmst_train_step")
+        self.arena.grads_zeroed = adam is not None   # the fused optimizer clears what it has consumed
         return pl.cv.view(pl.loss, 1)
 
     def _side_stream(self, main):
@@ -852,6 +855,7 @@ class Engine:
         Arena.reduce_segments() ('decoder', 'cross', 'modal_l5' ... 'modal_l0', 'embed') have been ENQUEUED;
         self.wstream then holds the last of them."""
         lib, ar, B, T, Lm = L.lib(), self.arena, pl.B, pl.T, pl.Lmem
+        ar.grads_zeroed = False
         m = self.model
         nl, ndl = m.num_encoder_layers, m.num_decoder_layers
         p_drop = LAYER_DROPOUT if train else 0.0

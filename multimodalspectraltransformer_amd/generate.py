@@ -35,6 +35,9 @@ def run_model(model, data_dict, config):
 
 
 D = 128
+# measurement hook (bench.py): a list that receives a (start, end) pair of torch.cuda.Event(enable_timing=True) around
+# every decoder-stack launch of the device beam search; None = off
+STEP_EVENTS = None
 
 
 class _StepState:
@@ -81,6 +84,7 @@ class _StepState:
             ss.kvc[l] = _P(pl.dec_acts[l]["kvc"])     # the sequences of a molecule share its memory rows (kv_group)
         ss.mem_bias = _P(pl.kbias_glob)
         ss.kv_group = rep
+        ss.rows_per_group = 1      # host-ranked beam search and greedy decode: one workgroup per sequence
         ss.embed = ar.p32("embed_trg.weight")
         ss.y = self.out.data_ptr()
         ss.w_out, ss.b_out = ar.pb("fc_out.weight"), ar.p32("fc_out.bias")
@@ -310,6 +314,94 @@ def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=Non
     return toks, smiles, conf
 
 
+class _BeamBuffers:
+    """Two alternating beam states (include/mmst.h: mmst_beam_state) for B molecules x W beams."""
+
+    def __init__(self, dev, B, W, cap):
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.seqs = [torch.zeros(B, W, cap + 1, **i32) for _ in range(2)]
+        self.probs = [torch.zeros(B, W, cap, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.scores = [torch.zeros(B, W, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.lens = [torch.zeros(B, W, **i32) for _ in range(2)]
+        self.nbeams = [torch.zeros(B, **i32) for _ in range(2)]
+        self.hist = [torch.zeros(B * W, cap, **i32) for _ in range(2)]
+        self.tok = torch.zeros(B * W, dtype=torch.long, device=dev)
+        self.state = []
+        for i in range(2):
+            st = L.BeamState()
+            st.seqs, st.probs, st.scores = self.seqs[i].data_ptr(), self.probs[i].data_ptr(), self.scores[i].data_ptr()
+            st.lens, st.nbeams, st.hist = self.lens[i].data_ptr(), self.nbeams[i].data_ptr(), self.hist[i].data_ptr()
+            self.state.append(st)
+        self.graphs = {}
+
+
+def _beam_search_device(model, pl, W, gen_len, sos, eos):
+    """Beam search without a host round trip per step: per position ONE decoder launch for all molecules x beams (the
+    beams of a molecule share a workgroup, the weights it streams and the molecule's memory keys/values) and ONE
+    bookkeeping launch (mmst_beam_step).  A beam's prefix is never copied: its history table names the cache rows.
+    The whole loop is captured in a hipGraph on first use and replayed afterwards (MMST_DECODE_GRAPH=0: plain
+    launches)."""
+    lib = L.lib()
+    B, cap = pl.B, pl.cap_T
+    key = "_beam_device_%d" % W
+    stt = getattr(pl, key, None)
+    if stt is None:
+        stt = _StepState(model, pl, rep=W)
+        stt.beam = _BeamBuffers(stt.logits.device, B, W, cap)
+        setattr(pl, key, stt)
+    bb = stt.beam
+    ar = model._engine.arena
+    pe = ar.p32("pe_trg.weight")
+    V = model.out_size
+
+    def run():
+        _cross_kv(model, pl)
+        L.check(lib.mmst_beam_init(C.byref(bb.state[0]), C.c_void_p(bb.tok.data_ptr()), B, W, cap, sos, L.stream_ptr()),
+                "mmst_beam_init")
+        ss = stt.stack
+        ss.kv_group, ss.rows_per_group = W, 0
+        for idx in range(gen_len):
+            ss.hist = bb.hist[idx & 1].data_ptr()
+            ev = None
+            if STEP_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            stt.stack_step(bb.tok.data_ptr(), pe, idx)
+            if ev is not None:
+                ev[1].record()
+                STEP_EVENTS.append(ev)
+            L.check(lib.mmst_beam_step(C.c_void_p(stt.logits.data_ptr()), VPAD, V, C.byref(bb.state[idx & 1]),
+                                       C.byref(bb.state[(idx + 1) & 1]), C.c_void_p(bb.tok.data_ptr()), B, W, cap, idx,
+                                       eos, L.stream_ptr()), "mmst_beam_step")
+        ss.hist = None
+
+    gkey = (gen_len, sos, eos, ar.weights_serial)
+    g = bb.graphs.get(gkey)
+    if g is not None:
+        g.replay()
+    else:
+        run()   # eager: also loads every kernel before a capture
+        if os.environ.get("MMST_DECODE_GRAPH", "1") != "0":
+            torch.cuda.synchronize()
+            out = [t[gen_len & 1].clone() for t in (bb.seqs, bb.lens, bb.scores, bb.probs)]
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                bb.graphs = {gkey: g}
+            except Exception:      # capture is an optimisation: plain launches stay correct
+                bb.graphs = {}
+            for t, o in zip((bb.seqs, bb.lens, bb.scores, bb.probs), out):
+                t[gen_len & 1].copy_(o)   # a capture executes nothing, but keep the eager results in any case
+    f = gen_len & 1
+    seqs, lens = bb.seqs[f].cpu().tolist(), bb.lens[f].cpu().tolist()
+    scores, probs = bb.scores[f].cpu().tolist(), bb.probs[f].cpu().tolist()
+    beams = []
+    for i in range(B):
+        beams.append([(scores[i][w], seqs[i][w][:lens[i][w]], probs[i][w][:lens[i][w] - 1]) for w in range(W)])
+    return beams
+
+
 def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
     """validate_generate_MMT_v15_4.py:1056-1094 with the reference's bookkeeping (:995-1053: de-duplication,
     finished beams carried over, score = product of the ranking probabilities, stable sort) but not its cost.
@@ -328,6 +420,12 @@ def beam_search(model, stoi, memory, src_padding_mask, config, beam_size):
         raise L.MMSTError(f"gen_len {gen_len} exceeds the plan's capacity of {pl.cap_T} target positions")
     lib, st = L.lib(), L.stream_ptr
     fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
+    if fused and W <= L.MAX_BEAM and os.environ.get("MMST_BEAM_HOST", "0") != "1":
+        was_training = model.training
+        model.eval()
+        out = _beam_search_device(model, pl, W, gen_len, sos, eos)
+        model.train(was_training)
+        return out
     key = "_beam_state_%d_%d" % (W, fused)
     stt = getattr(pl, key, None)
     if stt is None:

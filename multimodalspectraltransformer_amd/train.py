@@ -211,7 +211,7 @@ class TransformerMultiGPU:
                 def cb(seg, user):
                     name = names.get(seg) or f"modal_l{seg - L.SEG_MODAL0}"
                     self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),))
-            loss = eng.train_step(pl, x, train=True, zero_grads=True, adam=adam, on_segment=cb)
+            loss = eng.train_step(pl, x, train=True, zero_grads=not ar.grads_zeroed, adam=adam, on_segment=cb)
             model._last_plan = pl
             if self.world > 1:
                 scale = self.reducer.finish()

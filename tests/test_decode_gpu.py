@@ -82,6 +82,8 @@ def _params_array(layers):
     (3, 1, 70, 16, 0, 2, False),      # first position: a single key
     (3, 1, 70, 16, 5, 2, True),
     (4, 2, 582, 140, 63, 3, True),    # two sequences per memory block (beams), benchmark memory length
+    (9, 3, 582, 64, 20, 2, True),     # three beams per molecule: one workgroup per molecule
+    (8, 4, 200, 64, 33, 2, False),    # four beams per molecule
     (1, 1, 9, 200, 131, 1, False),    # more cached positions than one batch of key loads covers
     (64, 1, 130, 64, 17, 6, True),
 ])
@@ -194,3 +196,126 @@ def test_stack_step_rejects_bad_arguments():
     assert lib.mmst_decoder_stack_step(1, p, C.byref(s), NH, None) != 0
     assert lib.mmst_decoder_stack_step(9, p, C.byref(s), NH, None) != 0          # too many layers
     assert lib.mmst_decoder_stack_step(1, p, C.byref(s), 4, None) != 0           # head count
+
+
+@pytest.mark.parametrize("W", [2, 3, 4])
+def test_grouped_stack_step_equals_one_workgroup_per_sequence(W):
+    """The beams of a molecule in ONE workgroup (weights and memory keys/values read once for all of them) against
+    one workgroup per sequence, on the same inputs; then the same step with the cached prefixes scattered over the
+    molecule's sequences and a history table that says where each position's row lives."""
+    dev, mols, Lm, cap, pos, nl = "cuda", 5, 301, 48, 21, 3
+    B = mols * W
+    gen = torch.Generator(device=dev).manual_seed(40 + W)
+    layers = [_layer_params(gen, dev) for _ in range(nl)]
+    params = _params_array(layers)
+    r = lambda *s: torch.randn(*s, generator=gen, device=dev)  # noqa: E731
+    V, VP = 43, 64
+    embed, pos_row = r(V, D) * 0.5, r(D) * 0.5
+    tok = torch.randint(0, V, (B,), generator=gen, device=dev)
+    w_out = torch.zeros(VP, D, device=dev)
+    w_out[:V] = r(V, D) * 0.2
+    w_out, b_out = w_out.bfloat16(), torch.zeros(VP, device=dev)
+    caches = [(r(B, cap, 3 * D) * 0.7).bfloat16() for _ in range(nl)]
+    kvc = [(r(mols, Lm, 2 * D) * 0.7).bfloat16() for _ in range(nl)]
+    bias = torch.zeros(mols, Lm, device=dev)
+    bias[:, 17:23] = 1.0
+    bias[1, 100:] = float("-inf")
+
+    def run(cs, rows_per_group, hist=None):
+        y = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+        logits = torch.zeros(B, VP, device=dev)
+        s = L.DecStackStep()
+        s.tok, s.embed, s.pos_row, s.y = tok.data_ptr(), embed.data_ptr(), pos_row.data_ptr(), y.data_ptr()
+        for l in range(nl):
+            s.qkv_cache[l], s.kvc[l] = cs[l].data_ptr(), kvc[l].data_ptr()
+        s.mem_bias = bias.data_ptr()
+        s.w_out, s.b_out, s.logits, s.ld_logits, s.n_out, s.V = w_out.data_ptr(), b_out.data_ptr(), logits.data_ptr(), VP, VP, V
+        s.B, s.pos, s.cap, s.L, s.kv_group, s.rows_per_group = B, pos, cap, Lm, W, rows_per_group
+        s.hist = hist.data_ptr() if hist is not None else None
+        L.check(L.lib().mmst_decoder_stack_step(nl, params, C.byref(s), NH, L.stream_ptr()), "stack_step")
+        torch.cuda.synchronize()
+        return y.float(), logits
+
+    c_ref = [c.clone() for c in caches]
+    y_ref, lg_ref = run(c_ref, 1)
+    c_grp = [c.clone() for c in caches]
+    y_grp, lg_grp = run(c_grp, 0)
+    # same arithmetic per row; only the batching of the online-softmax rescales differs
+    assert float((y_grp - y_ref).abs().max()) < 2e-2
+    assert float((lg_grp - lg_ref).abs().max()) < 2e-2
+    for l in range(nl):
+        assert float((c_grp[l].float() - c_ref[l].float()).abs().max()) < (1e-6 if l == 0 else 3e-2)
+    # history: position t of sequence (m, w) is stored in the cache of sequence (m, perm[m, w, t])
+    perm = torch.stack([torch.stack([torch.randperm(W, generator=gen, device=dev) for _ in range(cap)], dim=1)
+                        for _ in range(mols)])                                  # [mols][W][cap]: slot <- (w, t)
+    hist = perm.reshape(B, cap).to(torch.int32).contiguous()
+    scattered = []
+    for l in range(nl):
+        c = caches[l].view(mols, W, cap, 3 * D)
+        sc = torch.zeros_like(c)
+        idx = perm.unsqueeze(-1).expand(-1, -1, -1, 3 * D)
+        sc.scatter_(1, idx, c)           # sc[m, perm[m, w, t], t] = c[m, w, t]
+        scattered.append(sc.view(B, cap, 3 * D).contiguous())
+    y_h, lg_h = run(scattered, 0, hist)
+    assert float((y_h - y_grp).abs().max()) == 0.0 and float((lg_h - lg_grp).abs().max()) == 0.0
+    # the new row goes to the sequence's OWN slot at `pos`
+    for l in range(nl):
+        assert torch.equal(scattered[l][:, pos], c_grp[l][:, pos])
+
+
+def test_beam_step_kernel_follows_the_reference_bookkeeping():
+    """mmst_beam_step against a host transcription of the reference's beam_search_step (validate_generate_MMT_v15_4.py
+    :995-1053) on random logits over several steps: sequences, lengths, double-precision scores, probabilities, the
+    tokens fed to the next decoder step and the history tables."""
+    dev, B, W, V, cap, eos, sos = "cuda", 7, 3, 43, 16, 2, 3
+    gen = torch.Generator(device=dev).manual_seed(9)
+    lib = L.lib()
+
+    def state():
+        t = dict(seqs=torch.zeros(B, W, cap + 1, dtype=torch.int32, device=dev),
+                 probs=torch.zeros(B, W, cap, device=dev), scores=torch.zeros(B, W, dtype=torch.float64, device=dev),
+                 lens=torch.zeros(B, W, dtype=torch.int32, device=dev), nbeams=torch.zeros(B, dtype=torch.int32, device=dev),
+                 hist=torch.zeros(B * W, cap, dtype=torch.int32, device=dev))
+        st = L.BeamState()
+        for k, v in t.items():
+            setattr(st, k, v.data_ptr())
+        return t, st
+    (ta, sa), (tb, sb) = state(), state()
+    tok = torch.zeros(B * W, dtype=torch.long, device=dev)
+    L.check(lib.mmst_beam_init(C.byref(sa), C.c_void_p(tok.data_ptr()), B, W, cap, sos, L.stream_ptr()), "beam_init")
+    beams = [[(1, [sos], [])] for _ in range(B)]
+    slots = [[0] for _ in range(B)]                 # slot of every reference beam in the device arrays
+    cur, nxt = (ta, sa), (tb, sb)
+    for pos in range(10):
+        logits = torch.randn(B * W, 64, generator=gen, device=dev) * 2.0
+        logits[:, eos] += 1.5                       # make finished beams common
+        L.check(lib.mmst_beam_step(C.c_void_p(logits.data_ptr()), 64, V, C.byref(cur[1]), C.byref(nxt[1]),
+                                   C.c_void_p(tok.data_ptr()), B, W, cap, pos, eos, L.stream_ptr()), "beam_step")
+        torch.cuda.synchronize()
+        probs = torch.softmax(logits[:, :V], dim=1).cpu()
+        for i in range(B):
+            new_beam = []
+            for j, (score, seq, pr) in enumerate(beams[i]):
+                if seq[-1] == eos:
+                    new_beam.append((score, seq, pr, j))
+                    continue
+                tp, ti = torch.topk(probs[i * W + j], W)
+                for k in range(W):
+                    p = float(tp[k])
+                    new_beam.append((score * p, seq + [int(ti[k])], pr + [p], j))
+            new_beam.sort(key=lambda x: x[0], reverse=True)
+            new_beam = new_beam[:W]
+            got_len = nxt[0]["lens"][i].tolist()
+            for w, (score, seq, pr, parent) in enumerate(new_beam):
+                assert got_len[w] == len(seq)
+                assert nxt[0]["seqs"][i, w, :len(seq)].tolist() == seq, (pos, i, w)
+                assert abs(float(nxt[0]["scores"][i, w]) - score) <= 1e-5 * abs(score)
+                np_ = nxt[0]["probs"][i, w, :len(pr)].tolist()
+                assert all(abs(a - b) < 1e-5 for a, b in zip(np_, pr))
+                assert int(tok[i * W + w]) == seq[-1]
+                h = nxt[0]["hist"][i * W + w].tolist()
+                assert h[pos] == parent and h[:pos] == cur[0]["hist"][i * W + parent, :pos].tolist()
+            beams[i] = [(b[0], b[1], b[2]) for b in new_beam]
+            assert int(nxt[0]["nbeams"][i]) == W
+        cur, nxt = nxt, cur
+    assert any(b[1][-1] == eos for bm in beams for b in bm)
