@@ -272,6 +272,48 @@ def multinomial_sequence(model, stoi, memory, src_padding_mask, config, generato
     return toks[1:], probs.transpose(0, 1)
 
 
+def multinomial_sequence_multi_2(model, memory, src_padding_mask, stoi, config, generator=None):
+    """mmt_result_test_functions_15_4.py:791-829: multinomial decode of max_len tokens for every column of `memory`
+    (callers duplicate the batch to draw several samples per molecule); returns tokens without <SOS> (max_len, N)
+    and the chosen tokens' probabilities with the first row dropped (max_len - 1, N), as the reference does."""
+    pl = _plan_for(model, memory)
+    toks, probs = _decode_plan(model, pl, config.max_len, config.temperature, stoi["<SOS>"], early_stop=False,
+                               sample=True, generator=generator)
+    return toks[1:, :], probs[1:, :]
+
+
+def predict_prop_correct_max_sequence(model, stoi, memory, src_padding_mask, trg_enc_SMI, gen_num, config,
+                                      generator=None):
+    """validate_generate_MMT_v15_4.py:309-431: per-token probabilities under teacher forcing.  The reference re-runs
+    the decoder on a growing prefix of the TRUE tokens for every position; under the causal mask the distribution it
+    reads at step idx is row idx of ONE teacher-forced pass over [<SOS>, true tokens...], which is what runs here.
+    Returns (trg_tensor (N, T), corr_token_prob (T, N), trg_tensor_max (N, T), max_token_prob (T, N),
+    multinom_token_prob (T * N,)) with T = trg_enc_SMI.shape[1] - 1; gen_num is ignored as in the reference (:386)."""
+    pl = _plan_for(model, memory)
+    eng = model._engine
+    B = pl.B
+    trg = trg_enc_SMI.to(eng.device, torch.int64)
+    T = trg.shape[1] - 1
+    if T > pl.cap_T:
+        raise L.MMSTError(f"target length {T} exceeds the plan's capacity of {pl.cap_T} positions")
+    was_training = model.training
+    model.eval()
+    real = trg.t()[1:, :]                                     # (T, N) true next tokens
+    tok = pl.cv.view(pl.tok, model.max_len + 1, B)
+    tok[0].fill_(stoi["<SOS>"])
+    tok[1:T].copy_(real[:T - 1])
+    eng.decode(pl, False, T=T)
+    logits = pl.cv.view(pl.logits, B, T, VPAD)[:, :, :model.out_size].transpose(0, 1)   # (T, N, V)
+    p = torch.softmax(logits / config.temperature, dim=2)
+    nxt = torch.argmax(p, dim=2)
+    max_prob = p.gather(2, nxt.unsqueeze(-1)).squeeze(-1)
+    corr = p.gather(2, real.unsqueeze(-1)).squeeze(-1)
+    sampled = torch.multinomial(p.reshape(-1, model.out_size), 1, generator=generator)
+    multinom = p.reshape(-1, model.out_size).gather(1, sampled).reshape(-1)
+    model.train(was_training)
+    return real.t().contiguous(), corr, nxt.t().contiguous(), max_prob, multinom
+
+
 def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=None, generator=None):
     """In-training generation, TransformerMultiGPU._generate_sequences (models_MMT_v15_4.py:1222-1297), on an encoded
     plan: max_len decode steps without early stop; returns the reference's (token tensor incl. <SOS>, SMILES list,

@@ -242,3 +242,39 @@ def test_timed_checkpoints_and_resume(tmp_path):
     for k in ("decoder.layers.0.linear1.weight", "encoder_cross.layers.0.self_attn.in_proj_weight", "fc_out.weight",
               "embed_trg.weight"):
         assert float((sa[k] - sb[k]).abs().max()) < 1e-6, k
+
+
+def test_teacher_forced_probabilities_and_multi_sample_multinomial():
+    """predict_prop_correct_max_sequence (validate_generate_MMT_v15_4.py:309-431) as ONE teacher-forced pass against
+    the oracle's prefix-by-prefix evaluation, and multinomial_sequence_multi_2 (mmt_result_test_functions_15_4.py:791)
+    on the fitted fixture model: shapes of the reference's return values, probabilities within 2e-2, argmax tokens
+    identical (every decision of that model is separated by more than 2 logit units)."""
+    name, mode = GREEDY[0]
+    g = load_golden(name)
+    tm, model, config, memory, mask, stoi, itos = _wrapper_on(g, mode)
+    model.eval()
+    batch = O.synthetic_batch(int(g["B"]), int(g["seed"]), mode)
+    trg = batch["trg_enc_SMI"]
+    N, T = trg.shape[0], trg.shape[1] - 1
+    out = gen.predict_prop_correct_max_sequence(model, stoi, memory, mask, trg.cuda(), 1, config)
+    trg_tensor, corr, trg_max, max_prob, multinom = out
+    assert trg_tensor.shape == (N, T) and corr.shape == (T, N) and trg_max.shape == (N, T) and max_prob.shape == (T, N)
+    assert multinom.shape == (T * N,)
+    assert torch.equal(trg_tensor.cpu(), trg[:, 1:])
+    cfg = O.default_cfg(training_mode=mode, num_encoder_layers=int(g["nl"]), num_decoder_layers=int(g["nl"]))
+    from tests.util import apply_trained
+    sd = apply_trained(O.make_state_dict(cfg, int(g["wseed"])), g)
+    with torch.no_grad():
+        omem, _, omask, _ = O.forward(sd, cfg, batch, None)
+        want = torch.softmax(O.decode_logits(sd, cfg, trg.t()[:-1, :], omem, omask), dim=2)    # (T, N, V)
+    real = trg.t()[1:, :]
+    np.testing.assert_allclose(corr.cpu().numpy(), want.gather(2, real.unsqueeze(-1)).squeeze(-1).numpy(), atol=2e-2)
+    np.testing.assert_allclose(max_prob.cpu().numpy(), want.max(dim=2).values.numpy(), atol=2e-2)
+    fitted = 57        # positions the fixture's readout was fitted on
+    assert torch.equal(trg_max.cpu()[:, :fitted], want.argmax(dim=2).t()[:, :fitted])
+    assert torch.equal(trg_max.cpu()[:, :fitted], trg[:, 1:1 + fitted])          # the fitted model predicts its targets
+    toks, probs = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config)
+    assert toks.shape == (config.max_len, N) and probs.shape == (config.max_len - 1, N)
+    assert float(probs.min()) > 0 and float(probs.max()) <= 1
+    # a confident model: sampling mostly reproduces the greedy tokens (one unlucky draw sends a molecule elsewhere)
+    assert float((toks.cpu()[:fitted] == torch.from_numpy(g["tokens"])[:fitted]).float().mean()) > 0.6
