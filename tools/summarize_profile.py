@@ -63,9 +63,10 @@ def main(tag, what, pmc_steps=0, unit="training step"):
                     f"{100 * float(r['TotalDurationNs']) / tot:.1f} | {'' if t is None else f'{t / 1e6:.1f}'} |\n")
         f.write(f"\nTotal GPU kernel time {tot / 1e6:.1f} ms over the run.\n")
         if pmc_steps:
+            plural = unit + ("es" if unit.endswith("ch") else "s")
             total = sum(v["hbm_bytes_per_launch"] * v["launches_in_pmc_run"] for v in traffic.values())
             f.write(f"\nHBM traffic (PMC, FETCH_SIZE doubled + WRITE_SIZE) summed over every kernel of the counter run: "
-                    f"{total / 1e9:.2f} GB in {pmc_steps} {unit}{"es" if unit.endswith("ch") else "s"} = {total / 1e9 / pmc_steps:.2f} GB per {unit} (includes the "
+                    f"{total / 1e9:.2f} GB in {pmc_steps} {plural} = {total / 1e9 / pmc_steps:.2f} GB per {unit} (includes the "
                     f"one-off launches of model set-up).\n")
     print("wrote profiles for", tag)
 
