@@ -128,9 +128,14 @@ class CLIPModel(nn.Module):
 
     # ------------------------------------------------------------------
     def _cb_features(self, x):
-        """ChemBERTa branch as the reference drives it (:265-277)."""
+        """ChemBERTa branch as the reference drives it (:265-277).  Without a tokenizer the SMILES model is called
+        with the target token ids and their padding mask as they are (a caller's own SMILES encoder)."""
         dev = self.config.device
         trg = x['trg_enc_SMI'].to(dev).transpose(0, 1)
+        if self.tokenizer is None:
+            ids = trg.transpose(0, 1)
+            _, feats = self.CB_model(ids, (ids != 0).long())
+            return feats
         smiles = hf.tensor_to_smiles(trg[1:, :], self.itos)
         tok = self.tokenizer(smiles, return_tensors='pt', padding=True)
         _, feats = self.CB_model(tok['input_ids'].to(dev), tok['attention_mask'].to(dev))

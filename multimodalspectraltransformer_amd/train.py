@@ -95,7 +95,8 @@ class FusedAdamW:
         self.step_count = 0
         model._external_optimizer = False
 
-    def step(self, mode, grad_scale=1.0):
+    def step(self, mode, grad_scale=1.0, ranges=None):
+        """ranges: [lo, hi) element ranges to update instead of the training mode's active parameters."""
         eng = self.model._engine
         ar = eng.arena
         if ar.M is None:
@@ -104,7 +105,7 @@ class FusedAdamW:
         self.step_count += 1
         ar.weights_serial += 1
         st = L.stream_ptr()
-        for lo, hi in ar.active_ranges(mode):
+        for lo, hi in (ranges if ranges is not None else ar.active_ranges(mode)):
             L.check(L.lib().mmst_adamw(C.c_void_p(ar.P.data_ptr() + 4 * lo), C.c_void_p(ar.G.data_ptr() + 4 * lo),
                                        C.c_void_p(ar.M.data_ptr() + 4 * lo), C.c_void_p(ar.V.data_ptr() + 4 * lo),
                                        C.c_void_p(ar.Pb.data_ptr() + 2 * lo), C.c_long(hi - lo), C.c_float(self.lr),

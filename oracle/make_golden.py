@@ -354,6 +354,80 @@ def clip_case(M, name, mode, nl, B, seed, wseed, hseed):
     print(name, 'loss', float(loss), 'losses', np_(losses.detach())[:4])
 
 
+def clip_train_case(M, name, mode, nl, B, seed, wseed, hseed, steps=3, lr_scale=0.01):
+    """Three optimisation steps of the reference's contrastive training: CLIPModel.forward (models_CLIP_v15_4.py:243-302)
+    under the optimizer CLIP_make builds (:99-106: AdamW over [SMILES model @ CB_lr, spectra model @ MT_lr, both heads @
+    MT_projection_lr with config.weight_decay], weight_decay=0.), eval mode so that the run is deterministic.  CLIP_make
+    itself cannot run here (it loads ChemBERTa from files outside the repository), so the SMILES branch is a stand-in
+    with the one trainable layer the reference leaves unfrozen (LL1, :74-79) applied to given features.  With the
+    learning rates of config_V8.json the loss of this random-weight model is chaotic from the first step (24.9, 47.3,
+    115.5: dot products of two 512-wide LayerNorm outputs at temperature 1), which no reduced-precision run can follow,
+    so the three rates are scaled by `lr_scale`; the scaled values are stored in the fixture."""
+    import itertools
+    import utils_MMT.models_CLIP_v15_4 as CL
+    cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.1)
+    cfg.CB_lr, cfg.MT_lr, cfg.MT_projection_lr = cfg.CB_lr * lr_scale, cfg.MT_lr * lr_scale, cfg.MT_projection_lr * lr_scale
+    ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
+    mt = M.MultimodalTransformer(cfg)
+    sd = O.make_state_dict(ocfg, wseed)
+    mt.load_state_dict(sd)
+    head = O.make_clip_head_state_dict(hseed)
+    b = O.synthetic_batch(B, seed, mode)
+    E = O.CLIP_DIMS["CB_embedding"]
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    raw = torch.from_numpy(rng.standard_normal((B, E)).astype(np.float32))
+    ll1_w = torch.from_numpy((np.eye(E) + 0.02 * rng.standard_normal((E, E))).astype(np.float32))
+    ll1_b = torch.from_numpy((0.02 * rng.standard_normal(E)).astype(np.float32))
+
+    class StandIn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.LL1 = torch.nn.Linear(E, E)
+
+        def forward(self, ids, mask):
+            return None, self.LL1(raw)
+
+    def tokenizer(smiles, return_tensors='pt', padding=True):
+        return {'input_ids': torch.zeros(len(smiles), 1, dtype=torch.long),
+                'attention_mask': torch.ones(len(smiles), 1, dtype=torch.long)}
+
+    cb_model = StandIn()
+    cb_model.LL1.load_state_dict({"weight": ll1_w, "bias": ll1_b})
+    itos = json.load(open(f'{REF}/itos.json'))
+    clip = CL.CLIPModel(cb_model, mt, tokenizer, itos, cfg)
+    clip.load_state_dict({**head, **{'MT_model.' + k: v for k, v in sd.items()},
+                          'CB_model.LL1.weight': ll1_w, 'CB_model.LL1.bias': ll1_b})
+    clip.eval()
+    params = [{"params": cb_model.parameters(), "lr": cfg.CB_lr},
+              {"params": mt.parameters(), "lr": cfg.MT_lr},
+              {"params": itertools.chain(clip.CB_projection.parameters(), clip.MT_projection.parameters()),
+               "lr": cfg.MT_projection_lr, "weight_decay": cfg.weight_decay}]
+    opt = torch.optim.AdamW(params, weight_decay=0.)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss, _ = clip({k: v.clone() for k, v in b.items()})
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    with torch.no_grad():
+        final, _ = clip({k: v.clone() for k, v in b.items()})
+    losses.append(float(final))
+    out = dict(step_losses=np.array(losses, np.float64), seed=np.int64(seed), wseed=np.int64(wseed), hseed=np.int64(hseed),
+               B=np.int64(B), nl=np.int64(nl), steps=np.int64(steps), ll1_weight_sum=np.float64(ll1_w.double().sum()),
+               lrs=np.array([cfg.CB_lr, cfg.MT_lr, cfg.MT_projection_lr, cfg.weight_decay], np.float64))
+    post = clip.state_dict()
+    for k in ('MT_projection.fc.weight', 'CB_projection.projection.weight', 'MT_projection.layer_norm.bias',
+              'MT_model.fp1.weight', 'MT_model.encoder_cross.layers.0.linear1.weight',
+              'MT_model.encoder_1H.layers.0.self_attn.in_proj_weight', 'CB_model.LL1.weight'):
+        out['post/' + k] = digest(post[k])
+        out['pre/' + k] = digest({**head, **{'MT_model.' + q: v for q, v in sd.items()}, 'CB_model.LL1.weight': ll1_w}[k])
+    untouched = 'decoder.layers.0.linear1.weight'      # no gradient from this loss: AdamW never touches it
+    assert torch.equal(post['MT_model.' + untouched], sd[untouched])
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+    print(name, 'step losses', losses)
+
+
 def text_case(hf, dl):
     stoi = json.load(open(f'{REF}/stoi.json'))
     itos = json.load(open(f'{REF}/itos.json'))
@@ -493,6 +567,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'clip':      # only the CLIP-head fixture
         clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
+        clip_train_case(M, 'clip_train_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=42, wseed=403, hseed=404)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'real_data':
         real_data_case(M)
@@ -521,6 +596,7 @@ def main():
     greedy_cases(M, vg)
     beam_case(M, vg, 'beam_c2_L2', '1H_HSQC_COSY_IR_MF_MW', 2, 6, seed=31, wseed=301, gain=6.0, beam_size=3, gen_len=12)
     clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
+    clip_train_case(M, 'clip_train_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=42, wseed=403, hseed=404)
     text_case(hf, dl)
     data_case(dl)
 

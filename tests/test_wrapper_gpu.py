@@ -278,3 +278,99 @@ def test_teacher_forced_probabilities_and_multi_sample_multinomial():
     assert float(probs.min()) > 0 and float(probs.max()) <= 1
     # a confident model: sampling mostly reproduces the greedy tokens (one unlucky draw sends a molecule elsewhere)
     assert float((toks.cpu()[:fitted] == torch.from_numpy(g["tokens"])[:fitted]).float().mean()) > 0.6
+
+
+def _clip_setup(g, tmp_path):
+    from multimodalspectraltransformer_amd.clip_functions import CLIPMultiGPU
+    model, config, cfg, sd, batch, db = build(g, MODE)
+    for k, v in dict(CB_embedding=1024, MT_embedding=512, projection_dim=512, dropout=0.1, CLIP_temperature=1,
+                     CLIP_model_save_dir=str(tmp_path), model_save_interval=10 ** 9, CLIP_continue_training=False).items():
+        setattr(config, k, v)
+    config.CB_lr, config.MT_lr, config.MT_projection_lr, config.weight_decay = (float(v) for v in g["lrs"])
+
+    E, B = 1024, int(g["B"])
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"]) + 1000))     # the generator's draws, in its order
+    raw = rng.standard_normal((B, E)).astype(np.float32)
+    ll1_w = (np.eye(E) + 0.02 * rng.standard_normal((E, E))).astype(np.float32)
+    ll1_b = (0.02 * rng.standard_normal(E)).astype(np.float32)
+    assert abs(float(ll1_w.sum()) - float(g["ll1_weight_sum"])) < 1e-3 * E
+
+    class StandIn(torch.nn.Module):            # the fixture's stand-in for the SMILES model: one trainable layer on given features
+        def __init__(self):
+            super().__init__()
+            self.LL1 = torch.nn.Linear(E, E)
+            self.register_buffer("raw", torch.from_numpy(raw))
+
+        def forward(self, ids, mask):
+            return None, self.LL1(self.raw)
+
+    cb = StandIn()
+    cb.LL1.load_state_dict({"weight": torch.from_numpy(ll1_w), "bias": torch.from_numpy(ll1_b)})
+    tm = CLIPMultiGPU(config, CB_model=cb, tokenizer=None, MT_model=model)
+    head = O.make_clip_head_state_dict(int(g["hseed"]))
+    tm.CLIP_model.load_state_dict(head, strict=False)
+    return tm, db, cb
+
+
+def test_clip_training_steps_vs_reference_fixture(tmp_path):
+    """Three steps of the contrastive training loop (loss, backward through heads / fp1 / encoders / the caller's
+    SMILES layer, three-group AdamW) against the same steps of the reference's CLIPModel under the optimizer CLIP_make
+    builds (eval mode, scaled learning rates: oracle/make_golden.py clip_train_case).  Losses within 6 % (the loss is a
+    log-softmax over dot products of 512-wide LayerNorm rows, see test_clip_head_vs_reference_fixture); the weight
+    movement of every sampled tensor points the way the reference's does (Adam's steps are sign-like, so the cosine
+    of the sampled deltas is the meaningful figure); parameters without a gradient stay untouched."""
+    g = load_golden("clip_train_c2_L1")
+    tm, db, cb = _clip_setup(g, tmp_path)
+    clip = tm.CLIP_model
+    before = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    ref = g["step_losses"]
+    losses = []
+    for i in range(int(g["steps"])):
+        out = tm.training_step(db, i, deterministic=True)
+        losses.append(float(out["loss"]))
+    final = float(tm.validation_step(db)["loss"])
+    losses.append(final)
+    print("clip step losses", losses, "reference", ref.tolist())
+    np.testing.assert_allclose(losses, ref, rtol=0.06)
+    assert losses[0] > losses[1] > losses[2] > losses[3]
+    after = clip.state_dict()
+    for k in ("MT_projection.fc.weight", "CB_projection.projection.weight", "MT_projection.layer_norm.bias",
+              "MT_model.fp1.weight", "MT_model.encoder_cross.layers.0.linear1.weight",
+              "MT_model.encoder_1H.layers.0.self_attn.in_proj_weight", "CB_model.LL1.weight"):
+        d_ref = (g["post/" + k] - g["pre/" + k])[3:]
+        d_got = (digest(after[k]) - digest(before[k]))[3:]
+        assert np.abs(d_ref).max() > 0
+        c = float(d_ref @ d_got / (np.linalg.norm(d_ref) * np.linalg.norm(d_got) + 1e-30))
+        print(k, "delta cosine", round(c, 4), "size", np.abs(d_got).max(), np.abs(d_ref).max())
+        assert c > 0.9, (k, c)
+        assert 0.7 < np.abs(d_got).max() / np.abs(d_ref).max() < 1.4, k
+    for k in ("MT_model.decoder.layers.0.linear1.weight", "MT_model.fc_out.weight", "MT_model.embed_trg.weight"):
+        assert torch.equal(after[k].cpu(), before[k].cpu()), k
+
+
+def test_clip_epoch_loop_saves_and_resumes(tmp_path):
+    """run_training_CLIP: epoch loop over weight-sorted batches, per-epoch .pth / .ckpt in the reference's naming,
+    the written configuration, the plateau scheduler on the epoch mean, and a resume from the .ckpt."""
+    from multimodalspectraltransformer_amd.clip_functions import CLIPMultiGPU, run_training_CLIP
+    g = load_golden("clip_train_c2_L1")
+    tm0, db, cb = _clip_setup(g, tmp_path)
+    config = tm0.config
+    seen = []
+    tm = run_training_CLIP(lambda e: [db, db], lambda e: [db], config, CB_model=cb, MT_model=tm0.CLIP_model.MT_model,
+                           num_epochs=2, log=seen.append)
+    assert len(seen) == 2 and "train_loss" in seen[0] and "test_loss" in seen[0], seen
+    files = sorted(os.listdir(tmp_path))
+    assert sum(f.startswith("MultimodalCLIP_Epoch_") and f.endswith(".pth") for f in files) == 2, files
+    assert sum(f.startswith("MultimodalCLIP_Epoch_") and f.endswith(".ckpt") for f in files) == 2, files
+    assert any(f.startswith("config_") and f.endswith(".json") for f in files)
+    assert tm.global_step == 4
+    ck = [f for f in files if f.startswith("MultimodalCLIP_Epoch_1_") and f.endswith(".ckpt")][0]
+    sd = torch.load(os.path.join(tmp_path, ck), map_location="cpu", weights_only=True)
+    assert all(k.startswith("CLIP_model.") for k in sd["state_dict"])
+    assert {"CLIP_model.MT_model.fp1.weight", "CLIP_model.MT_projection.fc.weight", "CLIP_model.CB_model.LL1.weight"} <= set(sd["state_dict"])
+    config.CLIP_continue_training, config.CLIP_model_path = True, os.path.join(tmp_path, ck)
+    tm2 = CLIPMultiGPU.load_from_checkpoint(config.CLIP_model_path, config=config, CB_model=cb)
+    a, b = tm.CLIP_model.state_dict(), tm2.CLIP_model.state_dict()
+    for k in ("MT_model.fp1.weight", "MT_projection.fc.weight", "MT_model.encoder_cross.layers.0.linear1.weight"):
+        assert torch.equal(a[k].cpu(), b[k].cpu()), k
+    assert tm2.current_epoch == 1

@@ -10,6 +10,7 @@ if args and args[0].startswith("fuse="):
     L.check(L.lib().mmst_ffn_config(int(args.pop(0)[5:])), "cfg")
 Ms = [int(a) for a in args] or [37248, 4032]
 dev = "cuda"
+DP = float(os.environ.get('FFN_DROP', '0.1'))
 for M in Ms:
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)
@@ -18,8 +19,8 @@ for M in Ms:
     h = torch.empty(M, 2048, device=dev, dtype=torch.bfloat16); z = torch.empty(M, 128, device=dev, dtype=torch.bfloat16)
     y = torch.empty_like(z); st = torch.empty(M, 2, device=dev)
     ws = torch.empty(8, M, 128, device=dev) if os.environ.get('FFN_WS') else None
-    fb = ops.ffn_batch([dict(X=x, W1=w1, W2=w2, b1=b1, H=h, ws=ws, drop_p=0.1, seed=7,
-                             epi=dict(Pn=M, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st, drop_p=0.1, seed=9))])
+    fb = ops.ffn_batch([dict(X=x, W1=w1, W2=w2, b1=b1, H=h, ws=ws, drop_p=DP, seed=7,
+                             epi=dict(Pn=M, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st, drop_p=DP, seed=9))])
     dzd = r(M, 128).bfloat16(); dz = r(M, 128).bfloat16(); dz1 = torch.empty_like(z); dzd1 = torch.empty_like(z)
     dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev)
     w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
