@@ -19,6 +19,7 @@
 #include "gemm_tile.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -350,40 +351,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   };
   // Second GEMM of chunk c2 and hidden-chunk arithmetic of chunk c in ONE hand-ordered region: the 16 MT MFMAs go
   // out MT at a time, each group followed by one 2-column piece of the bias/ReLU/dropout/convert work (8 MT pieces
-  // over 16 slots), so the vector ALU runs in the shadow of the matrix pipe.  c2 < 0: arithmetic only.  c < 0:
-  // MFMAs only.
-  auto gemm2_hidden = [&](int c2, int c) {
+  // over 16 slots), so the vector ALU runs in the shadow of the matrix pipe.  has2 / hasc are compile-time (the region
+  // stays free of branches): whether there is a second GEMM (chunk c2) / hidden-chunk arithmetic (chunk c).
+  auto gemm2_hidden = [&](auto has2_, auto hasc_, int c2, int c) {
+    constexpr bool has2 = decltype(has2_)::value, hasc = decltype(hasc_)::value;
     const unsigned char* img = w2s + (c2 & 1) * SLOT;
     const uint32_t chunk_pt = (uint32_t)(c * (HC / 2)) * ATTN_PAIR_MUL;
     bf16x8 qf[2][4];
     float bv[2][8];
     uint32_t hn[MT][2][4];
-    if (c2 >= 0) {
+    if constexpr (has2) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) qf[0][nt] = frag_n<true>(img, qrow(nt), 0, lane);
     }
-    if (c >= 0) {
+    if constexpr (hasc) {
 #pragma unroll
       for (int tp = 0; tp < 2; ++tp) load8f(bv[tp], b1s + c * HC + tp * 32 + 8 * q);
     }
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
       const int ks = grp >> 1, nt0 = (grp & 1) * 4;
-      if (c2 >= 0 && grp + 1 < 4) {
+      if constexpr (has2) {
+        if (grp + 1 < 4) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          qf[(grp + 1) & 1][nt] = frag_n<true>(img, qrow(((grp + 1) & 1) * 4 + nt), (grp + 1) >> 1, lane);
+          for (int nt = 0; nt < 4; ++nt)
+            qf[(grp + 1) & 1][nt] = frag_n<true>(img, qrow(((grp + 1) & 1) * 4 + nt), (grp + 1) >> 1, lane);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (c2 >= 0) {
+        if constexpr (has2) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[grp & 1][j], hfp[mt][ks], acc[mt][nt0 + j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int slot = grp * 4 + j;
-        if (c >= 0 && (MT == 2 || (slot & 1) == 0)) {
+        if (hasc && (MT == 2 || (slot & 1) == 0)) {
           const int piece = MT == 2 ? slot : slot >> 1;
           const int tp = MT == 2 ? piece >> 3 : piece >> 2, mt = MT == 2 ? (piece >> 2) & 1 : 0, e = (piece & 3) * 2;
           float v0 = a1[mt][2 * tp + (e >> 2)][e & 3], v1 = a1[mt][2 * tp + (e >> 2)][(e & 3) + 1];
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (c >= 0) {
+    if constexpr (hasc) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -416,6 +420,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
         }
     }
   };
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
 
   // prologue: step 0 has no second GEMM
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -423,27 +429,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   issue_w1(c0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (c0 + 1 < c1) issue_w1(c0 + 1);
+  issue_w1(c0 + 1);   // a workgroup walks at least four chunks
   issue_w2(c0);
   gemm1(c0);
-  gemm2_hidden(-1, c0);
+  gemm2_hidden(no, yes, -1, c0);
 
   auto wait_images = [&]() {   // everything older than the 2 MT hidden-activation stores of the previous step
     if (MT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
-  for (int c = c0 + 1; c < c1; ++c) {
+  // last_ (compile-time): the final chunk, no further first-GEMM image to request
+  auto step = [&](auto last_, int c) {
     wait_images();   // both images of this step have landed
     __builtin_amdgcn_s_barrier();
-    if (c + 1 < c1) issue_w1(c + 1);
+    if constexpr (!decltype(last_)::value) issue_w1(c + 1);
     issue_w2(c);
     gemm1(c);
     __builtin_amdgcn_sched_barrier(0);
-    gemm2_hidden(c - 1, c);
-  }
+    gemm2_hidden(yes, yes, c - 1, c);
+  };
+  for (int c = c0 + 1; c + 1 < c1; ++c) step(no, c);
+  step(yes, c1 - 1);
   wait_images();
   __builtin_amdgcn_s_barrier();
-  gemm2_hidden(c1 - 1, -1);
+  gemm2_hidden(yes, no, c1 - 1, -1);
 
   if (pr.hsplit > 1) store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
   else epi_ln(acc, pr.epi, p0, pw0, lane);
