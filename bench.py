@@ -236,7 +236,10 @@ def main():
     # events on its own stream during the timed steps
     tap = rank == 0 and not args.no_tap
     if tap:
-        L.check(lib.mmst_tap_config(L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
+        # the kernel with the largest share of GPU time (profiles/): the recomputing feed-forward weight-gradient kernel,
+        # or, with stored hidden gradients (MMST_FFN_WGRAD_RECOMPUTE=0), the split-K weight-gradient GEMM
+        recompute = lib.mmst_ffn_wgrad_mode() == 1
+        L.check(lib.mmst_tap_config(100 if recompute else L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
     gaps = os.environ.get("MMST_BENCH_GAPS") == "1"   # diagnostic: GPU idle time between consecutive steps
     evs = []
     t0 = time.perf_counter()
@@ -303,7 +306,9 @@ def main():
             lib.mmst_tap_read(C.byref(ms), C.byref(cnt), C.byref(flop), C.byref(byts), name, 128)
             if cnt.value > 0:
                 avg_s = ms.value / 1000.0 / cnt.value
-                bound = os.environ.get("MMST_TAP_BOUND", "hbm")
+                # the roof that binds: the larger of bytes / HBM peak and flops / MFMA peak per launch
+                t_hbm, t_mfma = byts.value / cnt.value / 8.0e12, flop.value / cnt.value / 2.5e15
+                bound = os.environ.get("MMST_TAP_BOUND") or ("hbm" if t_hbm >= t_mfma else "mfma")
                 if bound == "hbm":
                     a = byts.value / cnt.value / avg_s / 1e9
                     res["roofline"] = {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s",
@@ -314,8 +319,11 @@ def main():
                 else:
                     a = flop.value / cnt.value / avg_s / 1e12
                     res["roofline"] = {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s",
-                                       "frac": a / 2500.0, "traffic": None, "kernel": name.value.decode(),
-                                       "launches": cnt.value, "avg_us": avg_s * 1e6}
+                                       "frac": a / 2500.0, "traffic": pmc_traffic(name.value.decode()),
+                                       "algorithmic_flops_per_launch": flop.value / cnt.value,
+                                       "algorithmic_bytes_per_launch": byts.value / cnt.value,
+                                       "hbm_frac": byts.value / cnt.value / avg_s / 8.0e12,
+                                       "kernel": name.value.decode(), "launches": cnt.value, "avg_us": avg_s * 1e6}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -96,9 +96,13 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_e
                                    const mmst_enc_bwd* w, float drop_p, void* stream);
 /* Both halves on two streams in one call; wstream is made to wait for stream where needed (on the completion event
  * of the kernel it depends on, not on a marker), the caller joins the streams after the last layer.
- * interleave == 0: all parameter gradients on wstream after the data phase.  interleave != 0: the feed-forward and
- * out_proj weight gradients are enqueued as soon as the feed-forward backward is (they then run beside the attention
- * backward of the same layer), the in_proj gradient after the rest of _data.  Same results as _bwd. */
+ * interleave bit 0 clear: all parameter gradients on wstream after the data phase; with recomputed feed-forward
+ * gradients (mmst_ffn_wgrad_config) those go first, at the start of the layer, since they read nothing the layer's
+ * backward produces.  Bit 0 set: the feed-forward and out_proj weight gradients are enqueued as soon as the
+ * feed-forward backward is (they then run beside the attention backward of the same layer), the in_proj gradient after
+ * the rest of _data.  Bit 1 set: wstream is already ordered behind the kernel that produced w->dzd2 (true when the
+ * previous call on these streams was this function for the layer above), so no marker is recorded on stream for the
+ * early start.  Same results as _bwd. */
 int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                                    const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, int interleave,
                                    void* stream, void* wstream);

@@ -112,11 +112,14 @@ int mmst_ffn_wgrad(const mmst_ffn_wgrad_batch* batch, void* stream);
 /* ---- process-wide configuration (not re-entrant, see the head of this file) ---- */
 /* launches with fewer 128-row tiles than this run the feed-forward block as two grouped GEMMs; negative = default */
 int mmst_ffn_config(int fuse_min_tiles);
-/* 1: feed-forward weight gradients of fused launches recompute the hidden gradient; 0 (default): read a stored one */
+/* 1 (default): feed-forward weight gradients of fused launches recompute the hidden gradient; 0: the backward kernel
+ * stores it and a split-K GEMM reads it; negative: back to the default */
 int mmst_ffn_wgrad_config(int recompute);
+int mmst_ffn_wgrad_mode(void);   /* the setting in force: 1 recompute, 0 stored */
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */
+#define MMST_TAP_FFN_WGRAD 100   /* as `epilogue`: the launches of mmst_ffn_wgrad's kernel (the other two arguments unused) */
 int mmst_tap_config(int epilogue, int p_contraction_major, int q_contraction_major, int capacity);
 int mmst_tap_reset(void);
 /* sum of the durations, number of timed launches, their algorithmic flops / bytes, the kernel's name */

@@ -62,11 +62,14 @@ int mmst_ffn_config(int fuse_min_tiles) {
   ffn_set_fuse_min_tiles(fuse_min_tiles);
   return MMST_OK;
 }
-// 1: feed-forward weight gradients of fused launches recompute the hidden gradient; 0: they read a stored one
+// 1: feed-forward weight gradients of fused launches recompute the hidden gradient; 0: they read a stored one;
+// negative: the default (recompute, or what MMST_FFN_WGRAD_RECOMPUTE says)
 int mmst_ffn_wgrad_config(int recompute) {
-  ffn_set_wgrad_recompute(recompute ? 1 : 0);
+  ffn_set_wgrad_recompute(recompute);
   return MMST_OK;
 }
+
+int mmst_ffn_wgrad_mode(void) { return ffn_wgrad_recompute(); }
 
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
 int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {

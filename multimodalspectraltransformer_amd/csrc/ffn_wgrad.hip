@@ -7,19 +7,26 @@
 // dh is recomputed here from dz and the saved hidden activation, so the backward pass never writes or re-reads a
 // [rows][2048] gradient: the only large HBM stream of this kernel is ONE read of h.
 //
-// Decomposition: a workgroup owns 128 hidden columns j (16 chunks) and 1/16 of the rows (16 row splits), and
-// keeps both 128x128 fp32 gradient tiles in accumulators for its whole life; they leave through LDS-staged,
-// 256-byte-contiguous fp32 atomics at the end (16 adds per gradient element per launch).  Rows are walked 32 at a
-// time: the dz, h and x tiles arrive by LDS-DMA into a double buffer (the tile of the next step is in flight
-// while this one is consumed); dh goes registers -> LDS -> transposing reads.  Workgroups of one row split sit on
-// one XCD (consecutive ids rotate over the 8 XCDs), so the dz / x tiles they share are served by that L2.
+// Decomposition: a workgroup owns 128 hidden columns j and 1/16 of the rows (16 row splits); each of its 8 waves
+// owns 16 of those columns for everything: g and dh for them, the [128 n][16 j] slice of dW2 and the [16 j][128 k]
+// slice of dW1, both in accumulators for the workgroup's whole life; they leave through LDS-staged fp32 atomics of
+// 256 contiguous bytes at the end (16 adds per gradient element per launch).  Rows are walked 32 at a time: the dz, h
+// and x tiles arrive by LDS-DMA into a ring of three (two steps in flight while one is consumed), one barrier per
+// step.  Nothing is written back to LDS inside a step: g is computed as D[m][j] (rows on the accumulator registers),
+// and the contraction index of the two gradient GEMMs is the step's 32 rows in exactly that register order
+// (k = 0..3 -> rows 4q..4q+3, k = 4..7 -> rows 16+4q..16+4q+3 for lane quarter q), so the masked g IS the
+// operand fragment of dW1, and the transposing LDS reads of h, dz and x use the same row order.
+// Workgroups of one row split sit on one XCD (consecutive ids rotate over the 8 XCDs), so the dz / x tiles they
+// share are served by that L2.
 #include "ffn.h"
 #include "gemm_tile.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int DM = 128, FF = 2048, JC = 128, NJ = FF / JC, RS = 16, STEP = 32;
-constexpr int NBUF = 3;
+constexpr int NBUF = 3;          // tile ring: a step's tiles are requested two steps ahead (four buffers: no faster alone, and
+                                 // 96 KiB of LDS keep the other stream's 64 KiB launches off the CU: measured slower in a step)
 constexpr int IMG = STEP * 256;   // one 32-row x 128-column bf16 tile, rows of 256 B
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -28,13 +35,25 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // byte offset of 16-byte chunk `ch` (8 columns) of row `r` inside a tile image: the swizzle of frag_t()
 __device__ __forceinline__ int img_off(int r, int ch) { return r * 256 + (((((ch >> 1) ^ fsw(r)) << 1) | (ch & 1)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch batch) {
-  // [3 buffers][dz | h | x images] then the dh image (reused as the atomic staging area at the end): 80 KiB.
-  // The launch adds 2 KiB of unused dynamic LDS so that at most ONE workgroup of this kernel fits a CU, while the
-  // register budget stays that of two waves per SIMD: the launches of the activation-gradient stream this kernel
-  // runs beside always find LDS and registers on every CU.
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * 3 * IMG + IMG];
-  unsigned char* dhimg = smem + NBUF * 3 * IMG;
+// Transposing fragment read over a 32-row tile in the row order above: lane i of each 16 receives column col0 + i,
+// lo = rows 4q..4q+3, hi = rows 16+4q..16+4q+3.  Inline assembly for the reason given at frag_t_issue().
+__device__ __forceinline__ void frag_rows32_issue(s16x4& lo, s16x4& hi, const unsigned char* img, int col0, int lane) {
+  const int krow = 4 * (lane >> 4) + ((lane & 15) >> 2), col = col0 + 4 * (lane & 3);
+  const int off = krow * 256 + (((col >> 4) ^ fsw(krow)) << 5) + (col & 15) * 2;   // fsw(krow + 16) == fsw(krow)
+  uint32_t a = (uint32_t)(uintptr_t)(LDS_AS const unsigned char*)(img + off);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(a));
+}
+__device__ __forceinline__ void lds_wait2(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+template <int JT>   // 16-column tiles per wave: 1 (8 waves) or 2 (4 waves)
+__global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradBatch batch) {
+  constexpr int NWAVE = 8 / JT;
+  // [NBUF buffers][dz | h | x images] = 72 KiB, reused as the fp32 staging tile of the final atomics (128 x 129 floats)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * 3 * IMG];
+  static_assert(NBUF * 3 * IMG >= 128 * 129 * 4, "staging tile");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = NJ * RS;
@@ -45,50 +64,43 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
   const int M = pr.M;
   const int nsteps = (M + STEP - 1) / STEP;
   const int s0 = (int)((long)nsteps * rs / RS), s1 = (int)((long)nsteps * (rs + 1) / RS);
-  const int q = lane >> 4;
-  const int pw0 = (wave >> 1) * 64, qw0 = (wave & 1) * 64;
+  const int q = lane >> 4, li = lane & 15;
+  const int jw = wave * 16 * JT;                             // this wave's hidden columns inside the block
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
 
-  // this wave's 32 rows of W2^T (hidden j0 + wave*32 ...), as MFMA A fragments with interleaved rows so that a
-  // lane ends up with 8 CONSECUTIVE hidden columns of dh
-  bf16x8 wt[2][4];
+  // W2^T rows of this wave's 16 hidden columns as the B operand of g = dz W2 (lane <-> column j, k = n)
+  bf16x8 wt[JT][4];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = lane & 15;
-    const int j = j0 + wave * 32 + 8 * (i >> 2) + 4 * t + (i & 3);
+  for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      wt[t][ks] = *reinterpret_cast<const bf16x8*>(pr.W2T + (size_t)j * DM + ks * 32 + 8 * q);
-  }
+      wt[jt][ks] = *reinterpret_cast<const bf16x8*>(pr.W2T + (size_t)(j0 + jw + jt * 16 + li) * DM + ks * 32 + 8 * q);
 
-  f32x4 aw2[4][4], aw1[4][4];
+  f32x4 aw2[JT][8], aw1[JT][8];   // dW2[n = 16 t + 4q + reg][j = li], dW1[j = 4q + reg][k = 16 t + li] per column tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { aw2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; aw1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // bias gradients: db1 from the dh values this lane produces (8 hidden columns, summed over rows across the
-  // 16 lanes of a quarter-wave at the end); db2 = column sums of dz, by the first hidden chunk of each row split
-  float b1p[8];
+    for (int t = 0; t < 8; ++t) { aw2[jt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; aw1[jt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // bias gradients: db1[j] from the dh values of this lane (column li, 8 rows per step; the 4 lane quarters are
+  // added at the end); db2[n] = column sums of dz, by the first 128 threads of the first hidden block of each row split
+  float b1p[JT];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) b1p[e] = 0.f;
+  for (int jt = 0; jt < JT; ++jt) b1p[jt] = 0.f;
   float b2p = 0.f;
   const bool do_b2 = j0 == 0 && tid < DM;
 
-  // per-lane source coordinates of this wave's 2 DMA instructions per image: image row r, logical chunk ch
-  int srow[2], sch[2];
+  // this lane's share of a step's DMA: JT instructions per image, 4 image rows each, logical chunk sch[]
+  int srow[JT], sch[JT];
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int r = wave * 8 + jj * 4 + (lane >> 4), s = lane & 15;
-    srow[jj] = r;
-    sch[jj] = (((s >> 1) ^ fsw(r)) << 1) | (s & 1);
+  for (int jj = 0; jj < JT; ++jj) {
+    srow[jj] = (wave * JT + jj) * 4 + q;
+    sch[jj] = (((li >> 1) ^ fsw(srow[jj])) << 1) | (li & 1);
   }
-  // the three 32-row tiles of (full) step s -> buffer b, by LDS-DMA
   auto stage = [&](int s, int b) {
-    unsigned char* base = smem + b * 3 * IMG;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < JT; ++jj) {
+      unsigned char* dst = smem + b * 3 * IMG + (wave * JT + jj) * 4 * 256;
       const size_t m = (size_t)(s * STEP + srow[jj]);
-      unsigned char* dst = base + (wave * 8 + jj * 4) * 256;
       __builtin_amdgcn_global_load_lds((gptr_t)(pr.dZ + m * DM + sch[jj] * 8), (lptr_t)(dst), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(pr.H + m * FF + j0 + sch[jj] * 8), (lptr_t)(dst + IMG), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(pr.X + m * DM + sch[jj] * 8), (lptr_t)(dst + 2 * IMG), 16, 0, 0);
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
   auto stage_ragged = [&](int s, int b) {
     unsigned char* base = smem + b * 3 * IMG;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < JT; ++jj) {
       const int m = s * STEP + srow[jj];
       uint4 a = make_uint4(0, 0, 0, 0), h = a, x = a;
       if (m < M) {
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
         h = *reinterpret_cast<const uint4*>(pr.H + (size_t)m * FF + j0 + sch[jj] * 8);
         x = *reinterpret_cast<const uint4*>(pr.X + (size_t)m * DM + sch[jj] * 8);
       }
-      unsigned char* dst = base + srow[jj] * 256 + (lane & 15) * 16;
+      unsigned char* dst = base + srow[jj] * 256 + li * 16;
       *reinterpret_cast<uint4*>(dst) = a;
       *reinterpret_cast<uint4*>(dst + IMG) = h;
       *reinterpret_cast<uint4*>(dst + 2 * IMG) = x;
@@ -118,97 +130,98 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
     const unsigned char* zimg = smem + b * 3 * IMG;
     const unsigned char* himg = zimg + IMG;
     const unsigned char* ximg = zimg + 2 * IMG;
-    // ---- g^T[j][m] = sum_n W2^T[j][n] dz[m][n] for this wave's 32 hidden columns and the step's 32 rows
-    f32x4 gacc[2][2];
+    // row-major dz fragments of both 16-row halves (A operand of g), then the transposed reads, four tiles ahead
+    bf16x8 zf[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) gacc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 zf[2];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        zf[u] = *reinterpret_cast<const bf16x8*>(zimg + img_off(u * 16 + (lane & 15), ks * 4 + q));
+        zf[u][ks] = *reinterpret_cast<const bf16x8*>(zimg + img_off(u * 16 + li, ks * 4 + q));
+    // transposed fragments: h for this wave's columns, then 16 operand tiles (dz^T 0..7 for dW2, x^T 0..7 for dW1)
+    // through a ring of PF register pairs, PF tiles in flight
+    constexpr int PF = JT == 2 ? 2 : 4;
+    s16x4 hlo[JT], hhi[JT], tlo[PF], thi[PF];
+    auto issue_tile = [&](int i, s16x4& lo, s16x4& hi) { frag_rows32_issue(lo, hi, i < 8 ? zimg : ximg, (i & 7) * 16, lane); };
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int jt = 0; jt < JT; ++jt) frag_rows32_issue(hlo[jt], hhi[jt], himg, jw + jt * 16, lane);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) issue_tile(i, tlo[i], thi[i]);
+    // ---- g[m][j] = sum_n dz[m][n] W2^T[j][n]: rows m = 16 u + 4q + reg on the registers, column j = li
+    f32x4 g[JT][2];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) g[jt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-          gacc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[t][ks], zf[u], gacc[t][u], 0, 0, 0);
-    }
-    // ---- dh = g * mask(h) -> bf16 -> dh image (row m, hidden columns wave*32 + 8q .. +7)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int off = img_off(u * 16 + (lane & 15), wave * 4 + q);
-      const bf16x8 h = *reinterpret_cast<const bf16x8*>(himg + off);
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float gv = e < 4 ? gacc[0][u][e] : gacc[1][u][e - 4];
-        o[e] = (bf16)((float)h[e] > 0.f ? gv * dscale : 0.f);
-        b1p[e] += (float)o[e];
-      }
-      *reinterpret_cast<bf16x8*>(dhimg + off) = o;
-    }
+          g[jt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[u][ks], wt[jt][ks], g[jt][u], 0, 0, 0);
     if (do_b2) {
 #pragma unroll 8
       for (int r = 0; r < STEP; ++r)
         b2p += (float)*reinterpret_cast<const bf16*>(zimg + img_off(r, tid >> 3) + (tid & 7) * 2);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // ---- dW2 += dz^T h ;  dW1 += dh^T x   (contraction over the step's 32 rows: one k-step each)
-    {
-      s16x4 plo[4], phi[4], qlo[4], qhi[4];
+    bf16x8 hf[JT], dh[JT];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) frag_t_issue(plo[mt], phi[mt], zimg, pw0 + mt * 16 + 4 * (lane & 3), 0, lane);
+    for (int i = 0; i < 16; ++i) {
+      s16x4& lo = tlo[i % PF];
+      s16x4& hi = thi[i % PF];
+      // tile i has landed once only the younger tiles' reads (two each) are outstanding; LDS reads return in order
+      const int younger = 2 * ((PF - 1) < (15 - i) ? (PF - 1) : (15 - i));
+      if (i == 0) {   // the h fragments are older than tile 0
+        if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi), "+v"(hlo[0]), "+v"(hhi[0]));
+        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo), "+v"(hi), "+v"(hlo[0]), "+v"(hhi[0]));
+        if constexpr (JT == 2) asm volatile("" : "+v"(hlo[1]), "+v"(hhi[1]));   // readable from here on, like hlo[0]
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        frag_t_issue(qlo[nt], qhi[nt], himg, qw0 + (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), 0, lane);
-      lds_wait4(plo[0], phi[0], plo[1], phi[1], plo[2], phi[2], plo[3], phi[3]);
-      lds_wait4(qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
-      bf16x8 pf[4], qf[4];
+        for (int jt = 0; jt < JT; ++jt) hf[jt] = frag_join(hlo[jt], hhi[jt]);
+      } else if (younger == 6) {
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo), "+v"(hi));
+      } else if (younger == 4) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo), "+v"(hi));
+      } else if (younger == 2) {
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+      }
+      const bf16x8 af = frag_join(lo, hi);
+      if (i + PF < 16) issue_tile(i + PF, lo, hi);
+      if (i == 8) {   // dh = g * mask(h): the A fragment of dW1 (lane <-> column j, k = the step's rows)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { pf[i] = frag_join(plo[i], phi[i]); qf[i] = frag_join(qlo[i], qhi[i]); }
+        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+          for (int e = 0; e < 8; ++e) {
+            const float gv = e < 4 ? g[jt][0][e] : g[jt][1][e - 4];
+            dh[jt][e] = (bf16)((float)hf[jt][e] > 0.f ? gv * dscale : 0.f);
+            b1p[jt] += (float)dh[jt][e];
+          }
+      }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          aw2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], aw2[mt][nt], 0, 0, 0);
-    }
-    {
-      s16x4 plo[4], phi[4], qlo[4], qhi[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) frag_t_issue(plo[mt], phi[mt], dhimg, pw0 + mt * 16 + 4 * (lane & 3), 0, lane);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        frag_t_issue(qlo[nt], qhi[nt], ximg, qw0 + (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), 0, lane);
-      lds_wait4(plo[0], phi[0], plo[1], phi[1], plo[2], phi[2], plo[3], phi[3]);
-      lds_wait4(qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
-      bf16x8 pf[4], qf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { pf[i] = frag_join(plo[i], phi[i]); qf[i] = frag_join(qlo[i], qhi[i]); }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          aw1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], aw1[mt][nt], 0, 0, 0);
+      for (int jt = 0; jt < JT; ++jt) {
+        if (i < 8) aw2[jt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, hf[jt], aw2[jt][i], 0, 0, 0);          // dz^T h
+        else aw1[jt][i - 8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh[jt], af, aw1[jt][i - 8], 0, 0, 0);        // dh^T x
+      }
     }
   };
 
   const int s1f = (s1 * STEP <= M) ? s1 : s1 - 1;   // steps [s0, s1f) are full; at most one ragged step follows
-  if (s0 < s1f) stage(s0, 0);
-  if (s0 + 1 < s1f) stage(s0 + 1, 1);
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i)
+    if (s0 + i < s1f) stage(s0 + i, i);
   int b = 0;
   for (int s = s0; s < s1f; ++s) {
-    // Tiles of this step have landed: own portions once only the 6 DMA instructions of the next step are still
-    // outstanding, everyone's after the barrier, which also frees the buffer of step s-1 and the dh image.
-    if (s + 1 < s1f) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    // Tiles of this step have landed: own portions once only the 3 JT DMA instructions of each younger step in flight
+    // are still outstanding, everyone's after the barrier, which also frees the buffer of step s-1.
+    const int younger = s1f - 1 - s;   // steps after this one
+    if (younger >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * JT * (NBUF - 2)) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * JT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    static_assert(NBUF == 3 || NBUF == 4, "tail waits");
     __builtin_amdgcn_s_barrier();
-    const int b2 = b == 0 ? 2 : b - 1;                // (b + 2) % 3
-    if (s + 2 < s1f) stage(s + 2, b2);
+    const int bn = b == 0 ? NBUF - 1 : b - 1;         // (b + NBUF - 1) % NBUF: the buffer of step s - 1
+    if (s + NBUF - 1 < s1f) stage(s + NBUF - 1, bn);
     step(b);
     b = b == NBUF - 1 ? 0 : b + 1;
   }
@@ -219,40 +232,45 @@ __global__ __launch_bounds__(256, 2) void ffn_wgrad_kernel(const FfnWgradBatch b
     step(0);
   }
 
-  // ---- both tiles leave as contiguous fp32 atomics: each wave transposes its 64x64 sub-tile through LDS
-  // (two passes of 32 rows) and adds whole 64-float row segments (256 bytes per wave instruction)
-  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 65);
-  auto flush = [&](f32x4 (&acc)[4][4], float* C, int ldc, int row_base, int col_base) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int mt = half * 2 + mh;
-        const int rl = mh * 16 + (lane & 15);
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            stg[rl * 65 + tp * 32 + 8 * q + e] = acc[mt][2 * tp][e];
-            stg[rl * 65 + tp * 32 + 8 * q + 4 + e] = acc[mt][2 * tp + 1][e];
-          }
-      }
-      __syncthreads();
-#pragma unroll 8
-      for (int r = 0; r < 32; ++r)
-        atomicAdd(C + (size_t)(row_base + pw0 + half * 32 + r) * ldc + col_base + qw0 + lane, stg[r * 65 + lane]);
-    }
-  };
+  // ---- both 128 x 128 tiles leave as contiguous fp32 atomics through one staging tile in LDS: every wave writes its
+  // slice, then adds 16 whole rows (two 256-byte wave instructions per row)
+  float* stg = reinterpret_cast<float*>(smem);
+  constexpr int RW = 128 / NWAVE;   // staging rows each wave adds
   if (s0 < s1) {
-    flush(aw2, pr.dW2, FF, 0, j0);      // dW2[n][j0 + j]
-    flush(aw1, pr.dW1, DM, j0, 0);      // dW1[j0 + j][k]
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = b1p[e];
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-      if ((lane & 15) == 0) atomicAdd(pr.db1 + j0 + wave * 32 + 8 * q + e, v);
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stg[(16 * t + 4 * q + e) * 129 + jw + jt * 16 + li] = aw2[jt][t][e];   // [n][j]
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < RW; ++r) {
+      const int n = wave * RW + r;
+      atomicAdd(pr.dW2 + (size_t)n * FF + j0 + lane, stg[n * 129 + lane]);
+      atomicAdd(pr.dW2 + (size_t)n * FF + j0 + 64 + lane, stg[n * 129 + 64 + lane]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stg[(jw + jt * 16 + 4 * q + e) * 129 + 16 * t + li] = aw1[jt][t][e];   // [j][k]
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < RW; ++r) {
+      const int j = wave * RW + r;
+      atomicAdd(pr.dW1 + (size_t)(j0 + j) * DM + lane, stg[j * 129 + lane]);
+      atomicAdd(pr.dW1 + (size_t)(j0 + j) * DM + 64 + lane, stg[j * 129 + 64 + lane]);
+    }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      float v = b1p[jt];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (q == 0) atomicAdd(pr.db1 + j0 + jw + jt * 16 + li, v);
     }
     if (do_b2) atomicAdd(pr.db2 + tid, b2p);
   }
@@ -266,7 +284,26 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
     const FfnWgradProb& p = b.p[i];
     if (p.M < 1 || !p.dZ || !p.H || !p.X || !p.W2T || !p.dW1 || !p.db1 || !p.dW2 || !p.db2) return MMST_ERR_ARG;
   }
-  hipLaunchKernelGGL(ffn_wgrad_kernel, dim3(b.n * NJ * RS), dim3(256), 2048, stream, b);
+  // 4 waves of 32 hidden columns (default) or 8 waves of 16: MMST_FFN_WGRAD_WAVES.  Alone on the GPU the 8-wave shape
+  // is faster (120 against 137 us at 37248 rows); inside a training step its two 168-register waves per SIMD leave no
+  // room for the 240-register feed-forward backward of the other stream (8.30 against 7.95 ms per step).
+  static const int waves = [] { const char* e = getenv("MMST_FFN_WGRAD_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  GemmTap& tap = g_gemm_tap;
+  const bool timed = tap.epi == TAP_FFN_WGRAD && tap.count < tap.capacity;
+  if (timed) {   // algorithmic work: three GEMMs over the rows; h, dz and x read once, both gradients read and written
+    for (int i = 0; i < b.n; ++i) {
+      tap.flops += 3.0 * 2.0 * b.p[i].M * (double)DM * FF;
+      tap.bytes += 2.0 * b.p[i].M * (double)(FF + 2 * DM) + 2.0 * DM * FF + 2.0 * 8.0 * DM * FF;
+    }
+    tap.pt = waves;
+    (void)hipEventRecord(tap.start[tap.count], stream);
+  }
+  // the 4-wave shape would fit a CU twice by registers and LDS; 10 KiB of unused dynamic LDS keep it to one workgroup
+  // per CU, so that a launch of the activation-gradient stream (64 KiB, one 240-register wave per SIMD) always finds
+  // room beside it
+  if (waves == 4) hipLaunchKernelGGL(ffn_wgrad_kernel<2>, dim3(b.n * NJ * RS), dim3(256), 10240, stream, b);
+  else hipLaunchKernelGGL(ffn_wgrad_kernel<1>, dim3(b.n * NJ * RS), dim3(512), 0, stream, b);
+  if (timed) (void)hipEventRecord(tap.stop[tap.count++], stream);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

@@ -50,6 +50,7 @@ int gemm_waves_for(int epi);   // waves per workgroup of the kernel variant that
 void gemm_kernel_name(int epi, bool pt, bool qt, char* out, int cap);
 
 // Diagnostic tap (bench.py): HIP events around every launch of ONE kernel variant, on the launch stream.
+constexpr int TAP_FFN_WGRAD = 100;   // tap selector: the recomputing feed-forward weight-gradient kernel (ffn_wgrad.hip)
 struct GemmTap {
   int epi, pt, qt;       // variant to time; epi < 0 = off
   int count, capacity;

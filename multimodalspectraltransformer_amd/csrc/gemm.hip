@@ -465,7 +465,9 @@ int gemm_waves_for(int epi) { return gemm_waves(epi); }
 
 // name of the kernel that serves (epi, pt, qt) launches with full tiles, as a profiler prints it
 void gemm_kernel_name(int epi, bool pt, bool qt, char* out, int cap) {
-  if (epi == EPI_ATOMIC && pt && qt && wgrad_dma_stages())
+  if (epi == TAP_FFN_WGRAD)
+    snprintf(out, cap, "ffn_wgrad_kernel<%d>", g_gemm_tap.pt == 8 ? 1 : 2);
+  else if (epi == EPI_ATOMIC && pt && qt && wgrad_dma_stages())
     snprintf(out, cap, "wgrad_dma_kernel<%d, %d>", wgrad_dma_stages() > 30 ? wgrad_dma_stages() - 30 : wgrad_dma_stages(),
              wgrad_dma_stages() > 30 ? 32 : 64);
   else

@@ -268,14 +268,20 @@ int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const 
 
 // Parameter gradients of a layer as grouped split-K launches.  WG_EARLY: linear2, linear1 and out_proj, whose
 // inputs exist once enc_bwd_ffn has run; WG_LATE: in_proj, which needs dqkv from enc_bwd_attn.
-enum { WG_EARLY = 1, WG_LATE = 2 };
+// WG_FFN_RECOMPUTED: the feed-forward gradients by the recomputing kernel, which reads only what exists BEFORE the
+// layer's backward starts (the incoming gradient, the saved activations); WG_SKIP_FFN: they have been launched already.
+enum { WG_EARLY = 1, WG_LATE = 2, WG_FFN_RECOMPUTED = 4, WG_SKIP_FFN = 8 };
+bool enc_recompute(int n, const mmst_enc_acts* a) {
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
+  return ffn_wgrad_recompute() && tiles >= ffn_fuse_min_tiles();   // as in enc_bwd_ffn
+}
 int enc_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                     const mmst_enc_bwd* w, float drop_p, int which, hipStream_t st) {
   GemmProb probs[4 * MMST_MAX_GROUPS];
-  int np = 0, tiles = 0;
-  for (int i = 0; i < n; ++i) tiles += (a[i].B * a[i].S + 127) / 128;
-  const bool recompute = ffn_wgrad_recompute() && tiles >= ffn_fuse_min_tiles();   // as in mmst_encoder_layer_bwd_data
-  if (recompute && (which & WG_EARLY)) {
+  int np = 0;
+  const bool recompute = enc_recompute(n, a);
+  if (recompute && (which & (WG_EARLY | WG_FFN_RECOMPUTED)) && !(which & WG_SKIP_FFN)) {
     FfnWgradBatch wb;
     wb.n = n;
     for (int i = 0; i < n; ++i) {
@@ -286,6 +292,7 @@ int enc_bwd_weights(int n, const mmst_enc_params* p, const mmst_enc_grads* g, co
     }
     RUN(launch_ffn_wgrad(wb, st));
   }
+  if (!(which & (WG_EARLY | WG_LATE))) return MMST_OK;
   for (int i = 0; i < n; ++i) {
     const int M = a[i].B * a[i].S;
     const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
@@ -375,21 +382,32 @@ int mmst_encoder_layer_bwd_weights(int n, const mmst_enc_params* p, const mmst_e
 // feed-forward and out_proj weight gradients (nearly all of the layer's weight-gradient work, HBM- and MFMA-heavy)
 // start on wstream as soon as the feed-forward backward is done and so run beside the attention backward
 // (VALU-bound) of the same layer instead of beside the next layer's feed-forward backward; the in_proj gradient
-// follows when dqkv exists ----
+// follows when dqkv exists.  With recomputed feed-forward gradients (and bit 0 clear) those are launched on wstream
+// before anything else of the layer; bit 1 of `interleave` set: the caller knows wstream to be ordered behind the
+// producer of the incoming gradient already (the previous call of this function for the layer above), so no marker
+// is recorded on `stream` for it ----
 int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                                    const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, int interleave,
                                    void* stream_, void* wstream_) {
   if (!enc_args_ok(n, p, g, a, w, nhead) || !wstream_ || stream_ == wstream_) return MMST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
   hipEvent_t done = nullptr;
+  // recomputed feed-forward gradients need nothing this layer's backward produces: they start with it, beside the
+  // feed-forward backward that streams the same saved activation
+  const bool ffn_first = enc_recompute(n, a) && !(interleave & 1);
+  if (ffn_first) {
+    if (!(interleave & 2)) RUN(stream_fork(st, wst));   // 2: wstream is already ordered behind the incoming gradient
+    RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_FFN_RECOMPUTED, wst));
+  }
   RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, st));
-  if (interleave) {
+  if (interleave & 1) {
     RUN(stream_fork(st, wst));
     RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
   }
   RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, &done));
   RUN(wait_for(wst, done));
-  return enc_bwd_weights(n, p, g, a, w, drop_p, interleave ? WG_LATE : (WG_EARLY | WG_LATE), wst);
+  return enc_bwd_weights(n, p, g, a, w, drop_p,
+                         ((interleave & 1) ? WG_LATE : (WG_EARLY | WG_LATE)) | (ffn_first ? WG_SKIP_FFN : 0), wst);
 }
 
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,

@@ -164,7 +164,7 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
     w.dzd2 = dr ? pl->cross_dzd[l] : w.dz2;
     w.prev_seed = l > 0 ? layer_seed(ar->step_seed, UID_CROSS + l - 1) : 0;
     RUN(mmst_encoder_layer_bwd_streams(1, pl->cross_p[l], pl->cross_g[l], pl->cross_a[l], &w, pl->cross_heads, dp,
-                                       layer_seed(ar->step_seed, UID_CROSS + l), 0, st, wst));
+                                       layer_seed(ar->step_seed, UID_CROSS + l), l < nl - 1 ? 2 : 0, st, wst));
   }
   if (ar->on_segment) ar->on_segment(MMST_SEG_CROSS, ar->user);
   // modality encoders: the top LayerNorm backward of every group reads its slice of the memory gradient
@@ -193,7 +193,7 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
       w[i].prev_seed = l > 0 ? layer_seed(ar->step_seed, UID_MODAL + l - 1) : 0;
     }
     RUN(mmst_encoder_layer_bwd_streams(n, pl->modal_p[l], pl->modal_g[l], pl->modal_a[l], w, 16, dp,
-                                       layer_seed(ar->step_seed, UID_MODAL + l), 0, st, wst));
+                                       layer_seed(ar->step_seed, UID_MODAL + l), l < nl - 1 ? 2 : 0, st, wst));
     if (ar->on_segment) ar->on_segment(MMST_SEG_MODAL0 + l, ar->user);
   }
   // embeddings
