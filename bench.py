@@ -238,7 +238,7 @@ def main():
     if tap:
         # the kernel with the largest share of GPU time (profiles/): the recomputing feed-forward weight-gradient kernel,
         # or, with stored hidden gradients (MMST_FFN_WGRAD_RECOMPUTE=0), the split-K weight-gradient GEMM
-        recompute = lib.mmst_ffn_wgrad_mode() == 1
+        recompute = lib.mmst_ffn_wgrad_mode() >= 1
         L.check(lib.mmst_tap_config(100 if recompute else L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
     gaps = os.environ.get("MMST_BENCH_GAPS") == "1"   # diagnostic: GPU idle time between consecutive steps
     evs = []

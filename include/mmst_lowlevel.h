@@ -112,10 +112,11 @@ int mmst_ffn_wgrad(const mmst_ffn_wgrad_batch* batch, void* stream);
 /* ---- process-wide configuration (not re-entrant, see the head of this file) ---- */
 /* launches with fewer 128-row tiles than this run the feed-forward block as two grouped GEMMs; negative = default */
 int mmst_ffn_config(int fuse_min_tiles);
-/* 1 (default): feed-forward weight gradients of fused launches recompute the hidden gradient; 0: the backward kernel
- * stores it and a split-K GEMM reads it; negative: back to the default */
+/* 1 (default) or 2: feed-forward weight gradients of fused launches recompute the hidden gradient, with the 4-wave
+ * or the 8-wave shape of the kernel; 0: the backward kernel stores it and a split-K GEMM reads it; negative: back to
+ * the default */
 int mmst_ffn_wgrad_config(int recompute);
-int mmst_ffn_wgrad_mode(void);   /* the setting in force: 1 recompute, 0 stored */
+int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1 or 2 */
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */

@@ -62,8 +62,8 @@ int mmst_ffn_config(int fuse_min_tiles) {
   ffn_set_fuse_min_tiles(fuse_min_tiles);
   return MMST_OK;
 }
-// 1: feed-forward weight gradients of fused launches recompute the hidden gradient; 0: they read a stored one;
-// negative: the default (recompute, or what MMST_FFN_WGRAD_RECOMPUTE says)
+// 1 / 2: feed-forward weight gradients of fused launches recompute the hidden gradient (4- / 8-wave kernel shape);
+// 0: they read a stored one; negative: the default (1, or what MMST_FFN_WGRAD_RECOMPUTE says)
 int mmst_ffn_wgrad_config(int recompute) {
   ffn_set_wgrad_recompute(recompute);
   return MMST_OK;

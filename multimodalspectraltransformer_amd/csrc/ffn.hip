@@ -662,18 +662,19 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
   return MMST_OK;
 }
 
-// Weight gradients of fused launches: 1 (default) = ffn_wgrad.hip recomputes the hidden gradient, which is then never
-// written or re-read as a [rows][2048] matrix (3.3 GB less HBM traffic per training step at 64 molecules, the
-// backward kernel 40 us shorter per layer); 0 = the backward kernel stores it and the grouped split-K GEMM consumes it.
-// Environment: MMST_FFN_WGRAD_RECOMPUTE.
+// Weight gradients of fused launches: 1 (default) or 2 = ffn_wgrad.hip recomputes the hidden gradient, which is then
+// never written or re-read as a [rows][2048] matrix (2.3 GB less HBM traffic per training step at 64 molecules, the
+// backward kernel 45 us shorter per layer), with its 4-wave (1) or 8-wave (2) shape; 0 = the backward kernel stores it
+// and the grouped split-K GEMM consumes it.  Environment: MMST_FFN_WGRAD_RECOMPUTE.
 int g_wgrad_recompute = -1;
 int ffn_wgrad_recompute() {
   if (g_wgrad_recompute < 0) {
     const char* e = getenv("MMST_FFN_WGRAD_RECOMPUTE");
-    g_wgrad_recompute = (e && atoi(e) == 0) ? 0 : 1;
+    const int v = e ? atoi(e) : 1;
+    g_wgrad_recompute = (v >= 0 && v <= 2) ? v : 1;
   }
   return g_wgrad_recompute;
 }
-void ffn_set_wgrad_recompute(int on) { g_wgrad_recompute = on < 0 ? -1 : (on ? 1 : 0); }   // negative: back to the default
+void ffn_set_wgrad_recompute(int on) { g_wgrad_recompute = on < 0 ? -1 : (on > 2 ? 1 : on); }   // negative: back to the default
 void ffn_set_fuse_min_tiles(int tiles) { g_fuse_min_tiles = tiles; }
 int ffn_fuse_min_tiles() { return fuse_min_tiles(); }

@@ -284,10 +284,10 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
     const FfnWgradProb& p = b.p[i];
     if (p.M < 1 || !p.dZ || !p.H || !p.X || !p.W2T || !p.dW1 || !p.db1 || !p.dW2 || !p.db2) return MMST_ERR_ARG;
   }
-  // 4 waves of 32 hidden columns (default) or 8 waves of 16: MMST_FFN_WGRAD_WAVES.  Alone on the GPU the 8-wave shape
-  // is faster (120 against 137 us at 37248 rows); inside a training step its two 168-register waves per SIMD leave no
-  // room for the 240-register feed-forward backward of the other stream (8.30 against 7.95 ms per step).
-  static const int waves = [] { const char* e = getenv("MMST_FFN_WGRAD_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  // 4 waves of 32 hidden columns (default) or 8 waves of 16 (setting 2 of mmst_ffn_wgrad_config).  Alone on the GPU the
+  // 8-wave shape is faster (120 against 137 us at 37248 rows); inside a training step its two 168-register waves per
+  // SIMD leave no room for the 240-register feed-forward backward of the other stream (8.30 against 7.95 ms per step).
+  const int waves = ffn_wgrad_recompute() == 2 ? 8 : 4;
   GemmTap& tap = g_gemm_tap;
   const bool timed = tap.epi == TAP_FFN_WGRAD && tap.count < tap.capacity;
   if (timed) {   // algorithmic work: three GEMMs over the rows; h, dz and x read once, both gradients read and written

@@ -515,7 +515,7 @@ int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
       tap.bytes += 2.0 * p.K * ((double)p.Pn + p.Qn) + out_bytes * p.Pn * (double)p.Qn +
                    ((epi == EPI_DRELU || epi == EPI_LN) ? 2.0 * p.Pn * (double)p.Qn : 0.0);
     }
-    hipEventRecord(tap.start[tap.count], stream);
+    (void)hipEventRecord(tap.start[tap.count], stream);
   }
   int rc;
   switch (epi) {
@@ -526,7 +526,7 @@ int launch_gemm(GemmBatch& b, int epi, bool pt, bool qt, hipStream_t stream) {
     case EPI_ATOMIC: rc = dispatch<EPI_ATOMIC>(b, pt, qt, total, stream); break;
     default: return MMST_ERR_ARG;
   }
-  if (timed) hipEventRecord(tap.stop[tap.count++], stream);
+  if (timed) (void)hipEventRecord(tap.stop[tap.count++], stream);
   if (rc != MMST_OK) return rc;
   MMST_CHECK_LAUNCH();
   return MMST_OK;

@@ -276,8 +276,17 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
         L.check(L.lib().mmst_ffn_config(-1), "cfg")
 
 
+@pytest.fixture(params=[1, 2])
+def wgrad_shape(request):
+    """Both workgroup shapes of the recomputing kernel: setting 1 (4 waves) and 2 (8 waves)."""
+    L.check(L.lib().mmst_ffn_wgrad_config(request.param), "mmst_ffn_wgrad_config")
+    assert L.lib().mmst_ffn_wgrad_mode() == request.param
+    yield request.param
+    L.check(L.lib().mmst_ffn_wgrad_config(-1), "mmst_ffn_wgrad_config")
+
+
 @pytest.mark.parametrize("M,groups,p", [(1024, 1, 0.0), (1000, 2, 0.1), (77, 1, 0.1), (8256, 1, 0.1)])
-def test_ffn_wgrad_recompute(M, groups, p):
+def test_ffn_wgrad_recompute(M, groups, p, wgrad_shape):
     """dW1/db1/dW2/db2 of the feed-forward block from (dz, h, x, W2^T) with dh recomputed in the kernel,
     accumulated on top of existing gradient content, against fp32 torch math."""
     gs, keep = [], []
