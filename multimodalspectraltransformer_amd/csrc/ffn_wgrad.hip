@@ -32,14 +32,20 @@ constexpr int IMG = STEP * 256;   // one 32-row x 128-column bf16 tile, rows of 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// byte offset of 16-byte chunk `ch` (8 columns) of row `r` inside a tile image: the swizzle of frag_t()
-__device__ __forceinline__ int img_off(int r, int ch) { return r * 256 + (((((ch >> 1) ^ fsw(r)) << 1) | (ch & 1)) << 4); }
+// Swizzle key of image row r (XORed into the index of a row's 32-byte granules): the key of the GEMM images.  With it
+// the transposing reads below are 2-way bank-conflicted (lane quarters 0/1 share an LDS cycle and read rows r, r + 4,
+// which have equal keys; 40 % of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT).  The conflict-free key
+// (r & 3) | ((r >> 2) & 1) << 2 was measured: no conflicts left, LDS cycles down by 38 %, yet the kernel alone takes
+// 171 us instead of 134 and a training step the same time, so the LDS array is not what bounds it; kept simple.
+__device__ __forceinline__ int rsw(int r) { return fsw(r); }
+// byte offset of 16-byte chunk `ch` (8 columns) of row `r` inside a tile image
+__device__ __forceinline__ int img_off(int r, int ch) { return r * 256 + (((((ch >> 1) ^ rsw(r)) << 1) | (ch & 1)) << 4); }
 
 // Transposing fragment read over a 32-row tile in the row order above: lane i of each 16 receives column col0 + i,
 // lo = rows 4q..4q+3, hi = rows 16+4q..16+4q+3.  Inline assembly for the reason given at frag_t_issue().
 __device__ __forceinline__ void frag_rows32_issue(s16x4& lo, s16x4& hi, const unsigned char* img, int col0, int lane) {
   const int krow = 4 * (lane >> 4) + ((lane & 15) >> 2), col = col0 + 4 * (lane & 3);
-  const int off = krow * 256 + (((col >> 4) ^ fsw(krow)) << 5) + (col & 15) * 2;   // fsw(krow + 16) == fsw(krow)
+  const int off = krow * 256 + (((col >> 4) ^ rsw(krow)) << 5) + (col & 15) * 2;   // rsw(krow + 16) == rsw(krow)
   uint32_t a = (uint32_t)(uintptr_t)(LDS_AS const unsigned char*)(img + off);
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(a));
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 #pragma unroll
   for (int jj = 0; jj < JT; ++jj) {
     srow[jj] = (wave * JT + jj) * 4 + q;
-    sch[jj] = (((li >> 1) ^ fsw(srow[jj])) << 1) | (li & 1);
+    sch[jj] = (((li >> 1) ^ rsw(srow[jj])) << 1) | (li & 1);
   }
   auto stage = [&](int s, int b) {
 #pragma unroll
