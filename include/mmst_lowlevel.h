@@ -94,10 +94,14 @@ typedef struct {
   void* H;                            /* [M][2048] hidden activation: written (forward), read (backward) */
   void* dH;                           /* optional [M][2048] hidden gradient (backward) */
   float* ws;                          /* optional fp32 [8][M][128]: hidden split for few row tiles */
+  const void* Wn; void* Cn;           /* optional (backward): Cn[M][128] = (epilogue output after its dropout) x Wn[128][128],
+                                       * the gradient through the linear layer in front of the block (out_proj); written
+                                       * only by the fused kernel without hidden split, see mmst_ffn */
   float drop_p; uint32_t seed;
   int tile_begin, hsplit;             /* launcher */
 } mmst_ffn_prob;
 typedef struct { int n; mmst_ffn_prob p[6]; } mmst_ffn_batch;
+/* returns 0, a negative error code, or (backward only) 1 when the launch also wrote every problem's Cn */
 int mmst_ffn(const mmst_ffn_batch* batch, int backward, void* stream);
 
 /* weight gradients of the block with the hidden gradient recomputed in the kernel (accumulating) */

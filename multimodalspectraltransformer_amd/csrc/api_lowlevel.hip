@@ -18,7 +18,8 @@ static_assert(sizeof(mmst_attn_prob) == sizeof(AttnProb) && sizeof(mmst_attn_bat
               offsetof(mmst_attn_prob, ldq) == offsetof(AttnProb, ldq) && offsetof(mmst_attn_prob, kv_rows) == offsetof(AttnProb, kv_rows) &&
               offsetof(mmst_attn_batch, p) == offsetof(AttnBatch, p), "attention ABI");
 static_assert(sizeof(mmst_ffn_prob) == sizeof(FfnProb) && sizeof(mmst_ffn_batch) == sizeof(FfnBatch) &&
-              offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit), "ffn ABI");
+              offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, Cn) == offsetof(FfnProb, Cn) &&
+              offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit), "ffn ABI");
 static_assert(sizeof(mmst_ffn_wgrad_prob) == sizeof(FfnWgradProb) && sizeof(mmst_ffn_wgrad_batch) == sizeof(FfnWgradBatch) &&
               offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M), "ffn weight-gradient ABI");
 static_assert(MMST_GEMM_MAX_GROUPS == GEMM_MAX_GROUPS && MMST_EPI_ATOMIC == EPI_ATOMIC && MMST_GF_OUT_F32 == GF_OUT_F32, "gemm ABI");
@@ -47,7 +48,10 @@ int mmst_attn_bwd(const mmst_attn_batch* batch, void* stream) {
 int mmst_ffn(const mmst_ffn_batch* batch, int backward, void* stream) {
   if (!batch) return MMST_ERR_ARG;
   FfnBatch b = *reinterpret_cast<const FfnBatch*>(batch);
-  return backward ? launch_ffn_bwd(b, (hipStream_t)stream) : launch_ffn_fwd(b, (hipStream_t)stream);
+  if (!backward) return launch_ffn_fwd(b, (hipStream_t)stream);
+  bool next_done = false;
+  const int rc = launch_ffn_bwd(b, (hipStream_t)stream, &next_done);
+  return rc != MMST_OK ? rc : (next_done ? 1 : 0);
 }
 
 // feed-forward weight gradients with the hidden gradient recomputed in the kernel (accumulating)

@@ -19,6 +19,8 @@ struct FfnProb {
   bf16* H;             // [M][2048] hidden activation after ReLU and dropout: written (forward), read (backward)
   bf16* dH;            // optional [M][2048] output of the backward kernel (gradient at the hidden pre-activation)
   float* ws;           // optional fp32 [FFN_MAX_HSPLIT][M][128]: enables the hidden-dimension split for few row tiles
+  const bf16* Wn;      // optional (backward, fused launches without hidden split): [128][128] weight of the linear layer
+  bf16* Cn;            //   that precedes the block; Cn[M][128] = E Wn, E = the epilogue's output after its dropout mask
   float drop_p;        // dropout on the hidden activation
   uint32_t seed;
   int tile_begin;      // filled by the launcher
@@ -48,7 +50,8 @@ struct FfnWgradBatch {
 int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream);
 
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream);
-int launch_ffn_bwd(FfnBatch& b, hipStream_t stream);
+// next_done (optional): set to whether the launch also produced Cn = E Wn (only the fused kernel without hidden split does)
+int launch_ffn_bwd(FfnBatch& b, hipStream_t stream, bool* next_done = nullptr);
 // Launches with fewer 128-row tiles than this run as two grouped GEMM launches instead of the fused kernel
 // (default 96, or the environment variable MMST_FFN_FUSE_MIN_TILES; negative restores the default).
 void ffn_set_fuse_min_tiles(int tiles);

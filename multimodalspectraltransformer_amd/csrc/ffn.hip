@@ -245,7 +245,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
     store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
   } else {
     __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
-    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+    if (pr.Wn == nullptr) {
+      epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+      return;
+    }
+    // Chained GEMM behind the epilogue: Cn = E Wn with E = the rows the epilogue has just produced (the gradient
+    // through the linear layer in front of the block), so those rows are not re-read by a separate launch.  Wn
+    // [k][j] arrives by LDS-DMA as two contraction-major images (k 0..63, 64..127) in the upper half of the ring while
+    // the epilogue runs (its scratch is the first NW KiB); E stays in registers as MFMA fragments.
+    unsigned char* wimg = smem + 2 * RSLOT;
+    {
+      constexpr int PER = 32 / (NW < 8 ? NW : 8);   // 32 instructions of 4 rows x 256 B over the first 8 waves
+      if (wave < 8) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const int piece = wave * PER + j, row = piece * 4 + (lane >> 4), s = lane & 15;
+          const int ch = (((s >> 1) ^ fsw(row & 63)) << 1) | (s & 1);   // logical 16-byte chunk that lands at position s
+          glds16(pr.Wn + row * DM + ch * 8, wimg + piece * 1024);
+        }
+      }
+    }
+    bf16x8 keep[MT][4];
+    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem, keep);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned char* img = wimg + (ks >> 1) * SLOT;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const bf16x8 wf = frag_t(img, (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks & 1, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, keep[mt][ks], acc[mt][nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = p0 + pw0 + mt * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[mt][2 * tp][e]; v[4 + e] = acc[mt][2 * tp + 1][e]; }
+        store8(pr.Cn + (size_t)m * DM + tp * 32 + 8 * q, v);
+      }
+    }
   }
 }
 
@@ -647,13 +697,22 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   return MMST_OK;
 }
 
-int launch_ffn_bwd(FfnBatch& b, hipStream_t stream) {
+int launch_ffn_bwd(FfnBatch& b, hipStream_t stream, bool* next_done) {
+  if (next_done) *next_done = false;
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
+  bool chained = true;
+  for (int i = 0; i < b.n; ++i) {
+    if ((b.p[i].Wn == nullptr) != (b.p[i].Cn == nullptr)) return MMST_ERR_ARG;
+    chained = chained && b.p[i].Wn != nullptr;
+  }
   const int nw = pick_waves(b, true);
   int total = prepare(b, true, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
   if (!split && total < fuse_min_tiles()) return ffn_bwd_unfused(b, stream);
+  if (split || !chained)   // the chained GEMM is all problems or none, and lives in the kernel without hidden split
+    for (int i = 0; i < b.n; ++i) b.p[i].Wn = nullptr;
+  else if (next_done) *next_done = true;
   if (nw == 4) launch_bwd_shape<4>(b, total, split, stream);
   else if (nw == 8) launch_bwd_shape<8>(b, total, split, stream);
   else launch_bwd_shape<10>(b, total, split, stream);

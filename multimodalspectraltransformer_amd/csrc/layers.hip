@@ -198,8 +198,9 @@ inline bool enc_args_ok(int n, const void* p, const void* g, const void* a, cons
 
 // first part of the critical path: feed-forward block backward fused with norm1 backward,
 // dz1 = LNbwd(((dzd2 W2) * mask(h)) W1 + dz2).  Leaves dh, dz1 and dzd1 in w.
+// *da_done: whether the launch also produced da = dzd1 Wo (the fused kernel chains that GEMM behind its epilogue).
 int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a, const mmst_enc_bwd* w,
-                float drop_p, uint32_t seed, hipStream_t st) {
+                float drop_p, uint32_t seed, hipStream_t st, bool* da_done) {
   FfnBatch fb;
   fb.n = n;
   int tiles = 0;
@@ -214,23 +215,25 @@ int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const 
     q.C2 = drop_p > 0.f ? (bf16*)w[i].dzd1 : nullptr;
     q.dgamma = g[i].g1; q.dbeta = g[i].be1;
     q.drop_p = drop_p; q.seed = seed + 8 * i + 1;
+    f.Wn = (const bf16*)p[i].w_o; f.Cn = (bf16*)w[i].da;
     fb.p[i] = f;
   }
-  return launch_ffn_bwd(fb, st);
+  return launch_ffn_bwd(fb, st, da_done);
 }
 
 // second part of the critical path: out_proj, attention and in_proj backward.  Leaves dqkv in w.
 int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const mmst_enc_bwd* w, int nhead, float drop_p,
-                 uint32_t seed, hipStream_t st, hipEvent_t* done = nullptr) {
+                 uint32_t seed, hipStream_t st, bool da_done, hipEvent_t* done = nullptr) {
   const int hd = D / nhead;
   GemmBatch gb;
   gb.n = n;
-  // da = dzd1 Wo
-  for (int i = 0; i < n; ++i) {
-    const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
-    gb.p[i] = dgrad(dzd1, a[i].B * a[i].S, D, p[i].w_o, D, w[i].da);
+  if (!da_done) {   // da = dzd1 Wo
+    for (int i = 0; i < n; ++i) {
+      const void* dzd1 = drop_p > 0.f ? w[i].dzd1 : w[i].dz1;
+      gb.p[i] = dgrad(dzd1, a[i].B * a[i].S, D, p[i].w_o, D, w[i].da);
+    }
+    RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
   }
-  RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
   // attention backward -> dqkv
   AttnBatch ab;
   memset(&ab, 0, sizeof(ab));
@@ -365,8 +368,9 @@ extern "C" {
 int mmst_encoder_layer_bwd_data(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                                 const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream_) {
   if (!enc_args_ok(n, p, g, a, w, nhead)) return MMST_ERR_ARG;
-  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, (hipStream_t)stream_));
-  return enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, (hipStream_t)stream_);
+  bool da_done = false;
+  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, (hipStream_t)stream_, &da_done));
+  return enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, (hipStream_t)stream_, da_done);
 }
 
 // ---- encoder layer backward, off the critical path: every parameter gradient of the layer as ONE grouped
@@ -399,12 +403,13 @@ int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_e
     if (!(interleave & 2)) RUN(stream_fork(st, wst));   // 2: wstream is already ordered behind the incoming gradient
     RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_FFN_RECOMPUTED, wst));
   }
-  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, st));
+  bool da_done = false;
+  RUN(enc_bwd_ffn(n, p, g, a, w, drop_p, seed, st, &da_done));
   if (interleave & 1) {
     RUN(stream_fork(st, wst));
     RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
   }
-  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, &done));
+  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, da_done, &done));
   RUN(wait_for(wst, done));
   return enc_bwd_weights(n, p, g, a, w, drop_p,
                          ((interleave & 1) ? WG_LATE : (WG_EARLY | WG_LATE)) | (ffn_first ? WG_SKIP_FFN : 0), wst);

@@ -65,7 +65,7 @@ def attn_bwd_launch(batch):
     L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
 
 
-_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws")
+_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws", "Wn", "Cn")
 
 
 def ffn_batch(groups):
@@ -88,7 +88,11 @@ def ffn_batch(groups):
 
 
 def ffn_launch(batch, backward=False):
-    L.check(L.lib().mmst_ffn(C.byref(batch), int(backward), L.stream_ptr()), "mmst_ffn")
+    """Returns 1 when a backward launch also wrote the chained Cn = E Wn of every problem, else 0."""
+    rc = L.lib().mmst_ffn(C.byref(batch), int(backward), L.stream_ptr())
+    if rc < 0:
+        L.check(rc, "mmst_ffn")
+    return rc
 
 
 def ffn_wgrad(groups):

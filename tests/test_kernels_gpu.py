@@ -232,16 +232,22 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
                                     drop_p=p, seed=200 + gi)))
             dzd, dz = bf(rnd(Mg, 128, seed=sd + 8)), bf(rnd(Mg, 128, seed=sd + 9))
             dz1 = torch.empty_like(y)
+            dzd1 = torch.empty_like(y) if p > 0 else None
             dh = torch.empty_like(h)
             dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+            # the GEMM chained behind the epilogue: Cn = (epilogue output after its dropout) Wn
+            wn = bf(rnd(128, 128, scale=0.09, seed=sd + 11))
+            cn = torch.full((Mg, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
             # backward epilogue = LayerNorm backward of an EARLIER norm: reuse (z, st, gam) of this call as its saved state
-            bw.append(dict(X=dzd, W1=w2.t().contiguous(), W2=w1.t().contiguous(), H=h, dH=dh, ws=ws, drop_p=p,
-                           epi=dict(Pn=Mg, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=db)))
-            keepers.append((x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db))
+            bw.append(dict(X=dzd, W1=w2.t().contiguous(), W2=w1.t().contiguous(), H=h, dH=dh, ws=ws, drop_p=p, Wn=wn, Cn=cn,
+                           epi=dict(Pn=Mg, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=db,
+                                    C2=dzd1, drop_p=p, seed=300 + gi)))
+            keepers.append((x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db, dzd1, wn, cn))
         ops.ffn_launch(ops.ffn_batch(fw), backward=False)
-        ops.ffn_launch(ops.ffn_batch(bw), backward=True)
+        chained = ops.ffn_launch(ops.ffn_batch(bw), backward=True)
+        assert chained == (1 if fused is True else 0)
         torch.cuda.synchronize()
-        for gi, (x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db) in enumerate(keepers):
+        for gi, (x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db, dzd1, wn, cn) in enumerate(keepers):
             Mg = x.shape[0]
             pre = torch.relu(x.float() @ w1.float().t() + b1)
             if p > 0:
@@ -272,6 +278,15 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
             close(dz1, zr.grad, rtol=3e-2, atol=3e-2)
             close(dg, gr.grad, rtol=2e-2, atol=2e-2)
             close(db, dy.sum(0), rtol=2e-2, atol=2e-2)
+            e_out = dz1
+            if p > 0:   # the epilogue's second output: dz1 through the dropout mask in front of the norm
+                keep3 = torch.from_numpy(keep_mask(300 + gi, np.arange(Mg * 128), p).reshape(Mg, 128)).to(DEV)
+                close(dzd1, dz1.float() * keep3 / (1 - p), rtol=1e-2, atol=1e-2)
+                e_out = dzd1
+            if chained:
+                close(cn, e_out.float() @ wn.float(), rtol=2e-2, atol=2e-2)
+            else:
+                assert bool(torch.isnan(cn.float()).all())   # untouched: the caller runs that GEMM itself
     finally:
         L.check(L.lib().mmst_ffn_config(-1), "cfg")
 
