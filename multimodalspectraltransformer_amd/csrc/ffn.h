@@ -42,6 +42,8 @@ struct FfnWgradProb {
   float* dW2; float* db2;   // [128][2048], [128]
   int M;
   float drop_p;
+  int tile_begin;      // filled by the launcher: first workgroup of this problem
+  int rs;              // filled by the launcher: row splits (1, 2, 4, 8 or 16), about 2300 rows each
 };
 struct FfnWgradBatch {
   int n;

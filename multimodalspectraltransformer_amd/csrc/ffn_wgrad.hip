@@ -7,10 +7,10 @@
 // dh is recomputed here from dz and the saved hidden activation, so the backward pass never writes or re-reads a
 // [rows][2048] gradient: the only large HBM stream of this kernel is ONE read of h.
 //
-// Decomposition: a workgroup owns 128 hidden columns j and 1/16 of the rows (16 row splits); each of its 8 waves
+// Decomposition: a workgroup owns 128 hidden columns j and one row split (about 2300 rows; 16 splits at 37248 rows); each of its waves
 // owns 16 of those columns for everything: g and dh for them, the [128 n][16 j] slice of dW2 and the [16 j][128 k]
 // slice of dW1, both in accumulators for the workgroup's whole life; they leave through LDS-staged fp32 atomics of
-// 256 contiguous bytes at the end (16 adds per gradient element per launch).  Rows are walked 32 at a time: the dz, h
+// 256 contiguous bytes at the end (one add per gradient element and row split).  Rows are walked 32 at a time: the dz, h
 // and x tiles arrive by LDS-DMA into a ring of three (two steps in flight while one is consumed), one barrier per
 // step.  Nothing is written back to LDS inside a step: g is computed as D[m][j] (rows on the accumulator registers),
 // and the contraction index of the two gradient GEMMs is the step's 32 rows in exactly that register order
@@ -62,14 +62,20 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
   static_assert(NBUF * 3 * IMG >= 128 * 129 * 4, "staging tile");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = NJ * RS;
-  const FfnWgradProb& pr = batch.p[blockIdx.x / per];
-  const int local = blockIdx.x % per;
-  const int rs = (local & 7) | (((local >> 3) & 1) << 3);   // ids equal mod 8 share a row split (one XCD)
-  const int j0 = (local >> 4) * JC;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < FFN_MAX_GROUPS; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) gi = i;
+  const FfnWgradProb& pr = batch.p[gi];
+  const int local = (int)blockIdx.x - pr.tile_begin;
+  const int nrs = pr.rs;                                    // row splits of this problem: a power of two <= RS
+  // consecutive workgroup ids rotate over the 8 XCDs: ids equal mod 8 (mod nrs when there are fewer splits) share a
+  // row split, so its dz / x tiles are fetched into one L2 (8 / nrs of them)
+  const int rs = nrs == RS ? ((local & 7) | (((local >> 3) & 1) << 3)) : (local & (nrs - 1));
+  const int j0 = (nrs == RS ? (local >> 4) : (local / nrs)) * JC;
   const int M = pr.M;
   const int nsteps = (M + STEP - 1) / STEP;
-  const int s0 = (int)((long)nsteps * rs / RS), s1 = (int)((long)nsteps * (rs + 1) / RS);
+  const int s0 = (int)((long)nsteps * rs / nrs), s1 = (int)((long)nsteps * (rs + 1) / nrs);
   const int q = lane >> 4, li = lane & 15;
   const int jw = wave * 16 * JT;                             // this wave's hidden columns inside the block
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
@@ -286,9 +292,19 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 
 int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
+  int total = 0;
   for (int i = 0; i < b.n; ++i) {
-    const FfnWgradProb& p = b.p[i];
+    FfnWgradProb& p = b.p[i];
     if (p.M < 1 || !p.dZ || !p.H || !p.X || !p.W2T || !p.dW1 || !p.db1 || !p.dW2 || !p.db2) return MMST_ERR_ARG;
+    // about 2300 rows (72 steps) per row split: a workgroup's fixed cost (its two 128 x 128 tiles leave as fp32
+    // atomics) stays a small part of its life, whatever the problem's size.  (16 splits for every problem made the
+    // grouped launch of the five modality encoders 1280 workgroups for the rows of one cross-encoder layer: 175 us
+    // against 131, and 7.93 against 7.69 ms per training step; 1200 or 4700 rows per split measure 7.73 / 7.86 ms.)
+    int rs = 1;
+    while (rs < RS && p.M > rs * 2328) rs *= 2;
+    p.rs = rs;
+    p.tile_begin = total;
+    total += NJ * rs;
   }
   // 4 waves of 32 hidden columns (default) or 8 waves of 16 (setting 2 of mmst_ffn_wgrad_config).  Alone on the GPU the
   // 8-wave shape is faster (120 against 137 us at 37248 rows); inside a training step its two 168-register waves per
@@ -307,8 +323,8 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
   // the 4-wave shape would fit a CU twice by registers and LDS; 10 KiB of unused dynamic LDS keep it to one workgroup
   // per CU, so that a launch of the activation-gradient stream (64 KiB, one 240-register wave per SIMD) always finds
   // room beside it
-  if (waves == 4) hipLaunchKernelGGL(ffn_wgrad_kernel<2>, dim3(b.n * NJ * RS), dim3(256), 10240, stream, b);
-  else hipLaunchKernelGGL(ffn_wgrad_kernel<1>, dim3(b.n * NJ * RS), dim3(512), 0, stream, b);
+  if (waves == 4) hipLaunchKernelGGL(ffn_wgrad_kernel<2>, dim3(total), dim3(256), 10240, stream, b);
+  else hipLaunchKernelGGL(ffn_wgrad_kernel<1>, dim3(total), dim3(512), 0, stream, b);
   if (timed) (void)hipEventRecord(tap.stop[tap.count++], stream);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
