@@ -21,14 +21,15 @@ inline GemmProb zero_prob() {
 
 // split-K factor for a weight-gradient GEMM: enough workgroups to fill the chip, few enough that the
 // fp32 atomic traffic (ksplit x output bytes) stays small
+// (environment MMST_KSPLIT_TARGET).  Default 48 when the feed-forward gradients have their own kernel: a layer's
+// projection gradients are then four output tiles over ~37000 rows, and 192 workgroups of ~12 steps each beat 512 of 5
+// (7.52 against 7.71 ms per training step; 36..56 measure the same); 128 when the grouped launch also carries the
+// feed-forward gradients (stored hidden gradient), the setting it was tuned for.
 inline int ksplit_target() {
-  static int t = 0;
-  if (!t) {
-    const char* e = getenv("MMST_KSPLIT_TARGET");
-    t = e ? atoi(e) : 128;
-    if (t < 1) t = 128;
-  }
-  return t;
+  const char* e = getenv("MMST_KSPLIT_TARGET");
+  const int t = e ? atoi(e) : 0;
+  if (t >= 1) return t;
+  return ffn_wgrad_recompute() ? 48 : 128;
 }
 inline int pick_ksplit(int Pn, int Qn, int K) {
   int tiles = ((Pn + 127) / 128) * ((Qn + 127) / 128);
