@@ -265,8 +265,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
         }
       }
     }
+    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+    // E as MFMA fragments: every lane reads back the 16-byte pieces it has just stored (its own writes, L2 hits);
+    // holding them in registers across the epilogue instead costs 32 registers there and 64 spilled ones
+    const bf16* E = pr.epi.C2 ? pr.epi.C2 : (const bf16*)pr.epi.C;
+    const int lde = pr.epi.C2 ? DM : pr.epi.ldc;
     bf16x8 keep[MT][4];
-    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem, keep);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = p0 + pw0 + mt * 16 + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) v = *reinterpret_cast<const uint4*>(E + (size_t)m * lde + ks * 32 + 8 * q);
+        keep[mt][ks] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll

@@ -231,12 +231,9 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
 // ---- LayerNorm backward on the same layout: dy = acc + R; C = dz, C2 = drop(dz); dgamma/dbeta column sums
 // (in-wave shuffles, then the NW waves through `smem`, >= NW KiB, which must be free of live data).
 // NW = waves of the workgroup that call it (4 or 8: 128-row tile, 1: a single wave with its rows).
-// keep (optional): receives what goes to C2 (C when there is no C2) as bf16 MFMA fragments, keep[mt][tp] = the 8
-// columns tp*32 + 8q .. +7 of row mt*16 + (lane & 15), zeros for rows past the end: the token-side operand of a
-// GEMM chained behind the epilogue.
 template <int NW = 4, int MT>
 __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[MT][8], const GemmProb& pr, int p0, int pw0, int lane, int wave,
-                                          int tid, unsigned char* smem, bf16x8 (*keep)[4] = nullptr) {
+                                          int tid, unsigned char* smem) {
   const int q = lane >> 4;
   auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
   const uint32_t thr = drop_threshold(pr.drop_p);
@@ -307,16 +304,7 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[MT][8], const GemmProb& p
           if (pr.drop_p > 0.f) drop8(dz, pr.seed, (uint32_t)m * 128u + n, thr, dscale);
           store8(pr.C2 + (size_t)m * 128 + n, dz);
         }
-        if (keep) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) keep[mt][tp][e] = (bf16)dz[e];
-        }
       }
-    } else if (keep) {
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) keep[mt][tp][e] = (bf16)0.f;
     }
   }
   // column sums over the tile's rows: 16 lanes (lane&15) in-wave, then the NW waves via LDS
