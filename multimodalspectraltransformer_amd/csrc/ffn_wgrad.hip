@@ -25,8 +25,11 @@
 namespace {
 
 constexpr int DM = 128, FF = 2048, JC = 128, NJ = FF / JC, RS = 16, STEP = 32;
-constexpr int NBUF = 3;          // tile ring: a step's tiles are requested two steps ahead (four buffers: no faster alone, and
-                                 // 96 KiB of LDS keep the other stream's 64 KiB launches off the CU: measured slower in a step)
+// Tile ring: a step's tiles are requested two steps ahead.  Measured alternatives: four buffers (no faster alone; 96 KiB
+// of LDS keep the other stream's 64 KiB launches off the CU: slower in a step); three buffers for h and two for the L2-
+// resident dz / x tiles (56 KiB, room for two attention workgroups beside: 145 us alone against 135, 7.56 against 7.50 ms
+// per step: what the kernels beside this one lack is registers, not LDS).
+constexpr int NBUF = 3;
 constexpr int IMG = STEP * 256;   // one 32-row x 128-column bf16 tile, rows of 256 B
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
