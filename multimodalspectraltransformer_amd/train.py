@@ -88,7 +88,8 @@ class GradReducer:
 
 class FusedAdamW:
     """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) on the flat parameter
-    buffer, one kernel per contiguous run of active parameters; also refreshes the bf16 weights."""
+    buffer: one launch over all the active parameter runs of the training mode (which also leaves their gradients
+    zeroed for the next step), or one launch per run for caller-given ranges; also refreshes the bf16 weights."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
@@ -105,7 +106,20 @@ class FusedAdamW:
         self.step_count += 1
         ar.weights_serial += 1
         st = L.stream_ptr()
-        for lo, hi in (ranges if ranges is not None else ar.active_ranges(mode)):
+        rs = list(ranges if ranges is not None else ar.active_ranges(mode))
+        if len(rs) <= 16 and ranges is None:
+            # every active range in one launch, which also leaves their gradients zeroed for the next step
+            lo = (C.c_long * len(rs))(*[r[0] for r in rs])
+            hi = (C.c_long * len(rs))(*[r[1] for r in rs])
+            L.check(L.lib().mmst_adamw_ranges(C.c_void_p(ar.P.data_ptr()), C.c_void_p(ar.G.data_ptr()),
+                                              C.c_void_p(ar.M.data_ptr()), C.c_void_p(ar.V.data_ptr()),
+                                              C.c_void_p(ar.Pb.data_ptr()), len(rs), lo, hi, C.c_float(self.lr),
+                                              C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                              C.c_float(self.wd), self.step_count, C.c_float(grad_scale), 1, st),
+                    "mmst_adamw_ranges")
+            ar.grads_zeroed = True
+            rs = []
+        for lo, hi in rs:
             L.check(L.lib().mmst_adamw(C.c_void_p(ar.P.data_ptr() + 4 * lo), C.c_void_p(ar.G.data_ptr() + 4 * lo),
                                        C.c_void_p(ar.M.data_ptr() + 4 * lo), C.c_void_p(ar.V.data_ptr() + 4 * lo),
                                        C.c_void_p(ar.Pb.data_ptr() + 2 * lo), C.c_long(hi - lo), C.c_float(self.lr),
@@ -202,19 +216,22 @@ class TransformerMultiGPU:
             pl = eng.plan(first.shape[0], T, self.config.training_mode)
             opt = self.optimizer
             adam = None
-            if self.world == 1:
+            # MMST_REDUCE_PATH=1 takes the several-rank host path (segment callbacks, separate optimizer launch) with
+            # one rank too, to time it on one GPU
+            ddp_path = self.world > 1 or os.environ.get("MMST_REDUCE_PATH") == "1"
+            if not ddp_path:
                 opt.step_count += 1
                 ar.weights_serial += 1
                 adam = (opt.step_count, opt.lr, opt.betas, opt.eps, opt.wd)
             names = {L.SEG_DECODER: "decoder", L.SEG_CROSS: "cross", L.SEG_EMBED: "embed"}
             cb = None
-            if self.world > 1:
+            if ddp_path:
                 def cb(seg, user):
                     name = names.get(seg) or f"modal_l{seg - L.SEG_MODAL0}"
                     self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),))
             loss = eng.train_step(pl, x, train=True, zero_grads=not ar.grads_zeroed, adam=adam, on_segment=cb)
             model._last_plan = pl
-            if self.world > 1:
+            if ddp_path:
                 scale = self.reducer.finish()
                 self.optimizer.step(self.config.training_mode, grad_scale=scale)
         else:
