@@ -65,6 +65,9 @@ typedef struct {  /* activations of ONE layer for ONE sequence group */
   void* z2; float* st2; /* pre-norm2 sum, (mean, rstd) */
   int B, S;
   int y_L, y_off;       /* if y_L > 0, output row (b, s) is written at row b*y_L + y_off + s of y */
+  void* hsign;          /* optional [B*S][64] uint32: one bit per entry of h (entry > 0, layout in mmst_lowlevel.h).  Used
+                           only under setting 3 of mmst_ffn_wgrad_config: _fwd writes it and the feed-forward backward
+                           reads these 256 B per row in place of the 4 KiB of h (the weight gradients still read h) */
 } mmst_enc_acts;
 
 typedef struct {  /* backward state of ONE layer for ONE sequence group */

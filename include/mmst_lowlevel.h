@@ -97,6 +97,11 @@ typedef struct {
   const void* Wn; void* Cn;           /* optional (backward): Cn[M][128] = (epilogue output after its dropout) x Wn[128][128],
                                        * the gradient through the linear layer in front of the block (out_proj); written
                                        * only by the fused kernel without hidden split, see mmst_ffn */
+  uint32_t* Hs;                       /* optional [M][64] sign words of H (bit set = entry > 0; word 16 q + j of a row  <->
+                                       * hidden columns 64 c + 32 t + 8 q + e, c = 2 j or 2 j + 1, t = 0..1, e = 0..7; the flag
+                                       * of (c, t, e) is bit (e odd ? 31 : 15) - 4 t - (e >> 1) - 8 (c & 1)):
+                                       * written by a forward launch; a backward launch that gets them for every problem,
+                                       * no dH and no hidden split reads these 256 B per row in place of the 4 KiB of H */
   float drop_p; uint32_t seed;
   int tile_begin, hsplit;             /* launcher */
 } mmst_ffn_prob;
@@ -118,10 +123,12 @@ int mmst_ffn_wgrad(const mmst_ffn_wgrad_batch* batch, void* stream);
 /* launches with fewer 128-row tiles than this run the feed-forward block as two grouped GEMMs; negative = default */
 int mmst_ffn_config(int fuse_min_tiles);
 /* 1 (default) or 2: feed-forward weight gradients of fused launches recompute the hidden gradient, with the 4-wave
- * or the 8-wave shape of the kernel; 0: the backward kernel stores it and a split-K GEMM reads it; negative: back to
- * the default */
+ * or the 8-wave shape of the kernel; 3: as 1, and the encoder layer entry points hand the sign words of the hidden
+ * activation (mmst_enc_acts.hsign) from the forward to the backward launch, which then does not read the hidden
+ * activation (2.4 GB less HBM traffic per training step at 64 molecules, 0.03 ms more time); 0: the backward kernel
+ * stores the hidden gradient and a split-K GEMM reads it; negative: back to the default */
 int mmst_ffn_wgrad_config(int recompute);
-int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1 or 2 */
+int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1, 2 or 3 */
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */

@@ -57,7 +57,7 @@ class AttnBatch(C.Structure):
 class FfnProb(C.Structure):
     _fields_ = [("epi", GemmProb), ("X", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("b1", C.c_void_p),
                 ("H", C.c_void_p), ("dH", C.c_void_p), ("ws", C.c_void_p), ("Wn", C.c_void_p), ("Cn", C.c_void_p),
-                ("drop_p", C.c_float), ("seed", C.c_uint32),
+                ("Hs", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
                 ("tile_begin", C.c_int), ("hsplit", C.c_int)]
 
 
@@ -131,7 +131,7 @@ class EncGrads(C.Structure):
 
 class EncActs(C.Structure):
     _fields_ = _ptrs("x", "y", "kbias", "qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2") + [
-        ("B", C.c_int), ("S", C.c_int), ("y_L", C.c_int), ("y_off", C.c_int)]
+        ("B", C.c_int), ("S", C.c_int), ("y_L", C.c_int), ("y_off", C.c_int), ("hsign", C.c_void_p)]
 
 
 class EncBwd(C.Structure):

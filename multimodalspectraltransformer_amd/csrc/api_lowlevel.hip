@@ -18,7 +18,7 @@ static_assert(sizeof(mmst_attn_prob) == sizeof(AttnProb) && sizeof(mmst_attn_bat
               offsetof(mmst_attn_prob, ldq) == offsetof(AttnProb, ldq) && offsetof(mmst_attn_prob, kv_rows) == offsetof(AttnProb, kv_rows) &&
               offsetof(mmst_attn_batch, p) == offsetof(AttnBatch, p), "attention ABI");
 static_assert(sizeof(mmst_ffn_prob) == sizeof(FfnProb) && sizeof(mmst_ffn_batch) == sizeof(FfnBatch) &&
-              offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, Cn) == offsetof(FfnProb, Cn) &&
+              offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, Cn) == offsetof(FfnProb, Cn) && offsetof(mmst_ffn_prob, Hs) == offsetof(FfnProb, Hs) &&
               offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit), "ffn ABI");
 static_assert(sizeof(mmst_ffn_wgrad_prob) == sizeof(FfnWgradProb) && sizeof(mmst_ffn_wgrad_batch) == sizeof(FfnWgradBatch) &&
               offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M) && offsetof(mmst_ffn_wgrad_prob, rs) == offsetof(FfnWgradProb, rs), "ffn weight-gradient ABI");
@@ -67,6 +67,7 @@ int mmst_ffn_config(int fuse_min_tiles) {
   return MMST_OK;
 }
 // 1 / 2: feed-forward weight gradients of fused launches recompute the hidden gradient (4- / 8-wave kernel shape);
+// 3: as 1 with the sign words of the hidden activation handed from the forward to the backward launch of a layer;
 // 0: they read a stored one; negative: the default (1, or what MMST_FFN_WGRAD_RECOMPUTE says)
 int mmst_ffn_wgrad_config(int recompute) {
   ffn_set_wgrad_recompute(recompute);

@@ -21,6 +21,10 @@ struct FfnProb {
   float* ws;           // optional fp32 [FFN_MAX_HSPLIT][M][128]: enables the hidden-dimension split for few row tiles
   const bf16* Wn;      // optional (backward, fused launches without hidden split): [128][128] weight of the linear layer
   bf16* Cn;            //   that precedes the block; Cn[M][128] = E Wn, E = the epilogue's output after its dropout mask
+  uint32_t* Hs;        // optional [M][64] sign words of H (bit set = entry > 0), 256 B per row in place of 4 KiB: written
+                       //   by the forward launch; a backward launch that gets them (and no dH) never reads H.  Word
+                       //   16 q + j of a row  <->  hidden columns 64 c + 32 t + 8 q + e, c = 2 j, 2 j + 1; the flag of
+                       //   (c, t, e) is bit (e odd ? 31 : 15) - 4 t - (e >> 1) - 8 (c & 1)
   float drop_p;        // dropout on the hidden activation
   uint32_t seed;
   int tile_begin;      // filled by the launcher
@@ -59,4 +63,5 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream, bool* next_done = nullptr);
 void ffn_set_fuse_min_tiles(int tiles);
 int ffn_fuse_min_tiles();
 int ffn_wgrad_recompute();          // see ffn.hip
+bool ffn_bwd_signs();               // see ffn.hip: setting 3 of ffn_wgrad_recompute()
 void ffn_set_wgrad_recompute(int on);

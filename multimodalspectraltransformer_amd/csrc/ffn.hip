@@ -68,13 +68,89 @@ template <int KIND> __device__ __forceinline__ constexpr uint32_t chunk_stride()
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Sign words (FfnProb::Hs): word 16 q + (c >> 1) of a row covers the hidden columns 64 c + 32 t + 8 q + e of the chunks
+// c = 2 j and 2 j + 1 (t = 0, 1; e = 0..7); the flag of (c, t, e) is bit sign_bit(c & 1, t, e).
+__host__ __device__ constexpr int tp_e_index(int t, int e) { return t * 4 + (e >> 1); }
+__host__ __device__ constexpr int sign_bit(int odd, int t, int e) { return ((e & 1) ? 31 : 15) - tp_e_index(t, e) - 8 * odd; }
+
+// Row epilogue of the fused backward kernels: LayerNorm backward of the block in front (epi_lnbwd, scratch = the first
+// NW KiB of smem), then optionally the chained GEMM Cn = E Wn with E = the rows the epilogue has just produced (the
+// gradient through the linear layer in front of the block), so those rows are not re-read by a separate launch.  Wn
+// [k][j] arrives by LDS-DMA as two contraction-major 16 KiB images (k 0..63, 64..127) at wimg while the epilogue runs.
+template <int NW, int MT>
+__device__ __forceinline__ void bwd_rows_epilogue(f32x4 (&acc)[MT][8], const FfnProb& pr, int p0, int pw0, int lane,
+                                                  int wave, int tid, unsigned char* smem, unsigned char* wimg) {
+  const int M = pr.epi.Pn, q = lane >> 4;
+  __syncthreads();  // the weight ring doubles as the column-sum scratch of the LayerNorm backward
+  if (pr.Wn == nullptr) {
+    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+    return;
+  }
+  {
+    constexpr int PER = 32 / (NW < 8 ? NW : 8);   // 32 instructions of 4 rows x 256 B over the first 8 waves
+    if (wave < 8) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int piece = wave * PER + j, row = piece * 4 + (lane >> 4), s = lane & 15;
+        const int ch = (((s >> 1) ^ fsw(row & 63)) << 1) | (s & 1);   // logical 16-byte chunk that lands at position s
+        glds16(pr.Wn + row * DM + ch * 8, wimg + piece * 1024);
+      }
+    }
+  }
+  epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
+  // E as MFMA fragments: every lane reads back the 16-byte pieces it has just stored (its own writes, L2 hits);
+  // holding them in registers across the epilogue instead costs 32 registers there and 64 spilled ones
+  const bf16* E = pr.epi.C2 ? pr.epi.C2 : (const bf16*)pr.epi.C;
+  const int lde = pr.epi.C2 ? DM : pr.epi.ldc;
+  bf16x8 keep[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = p0 + pw0 + mt * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < M) v = *reinterpret_cast<const uint4*>(E + (size_t)m * lde + ks * 32 + 8 * q);
+      keep[mt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned char* img = wimg + (ks >> 1) * SLOT;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const bf16x8 wf = frag_t(img, (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks & 1, lane);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, keep[mt][ks], acc[mt][nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = p0 + pw0 + mt * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[mt][2 * tp][e]; v[4 + e] = acc[mt][2 * tp + 1][e]; }
+      store8(pr.Cn + (size_t)m * DM + tp * 32 + 8 * q, v);
+    }
+  }
+}
+
 // ---- backward (activation gradients) ----------------------------------------------------------------------
 // Same chained-GEMM structure with the transposed weight copies, so both GEMMs read row-major images:
 //   g  = dz W2        first GEMM, weight image from W2^T [2048][128]
 //   dh = g * mask(h)  mask = saved hidden activation > 0 (ReLU and dropout at once), h tile by LDS-DMA
 //   dx += dh W1       second GEMM, weight image from W1^T [128][2048]
 // Three images per chunk through a ring of four slots, three images ahead, one barrier per image.
-template <bool SPLIT, int NW>
+template <bool SPLIT, int NW, bool SIGNS = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const FfnBatch batch) {
   typedef Shape<NW> S;
   constexpr int MT = S::MT, WD = S::WD, HD = S::HD, RSLOT = S::RSLOT;
@@ -108,6 +184,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
     }
     hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;
   }
+  // SIGNS: the mask comes from the sign words of the rows (FfnProb::Hs), held in registers for the whole hidden
+  // dimension and shifted down 16 bits per chunk; there is no hidden-activation image and nothing is stored in the loop
+  uint32_t mk[SIGNS ? MT : 1][16];
+  if constexpr (SIGNS) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = p0 + pw0 + mt * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pr.Hs + (size_t)(m < M ? m : M - 1) * 64 + q * 16 + j * 4);
+        mk[mt][4 * j] = v.x; mk[mt][4 * j + 1] = v.y; mk[mt][4 * j + 2] = v.z; mk[mt][4 * j + 3] = v.w;
+      }
+    }
+  }
   // optional copy of dh for a separate weight-gradient pass; zero records = every store dropped
   const auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(pr.dH ? pr.dH : pr.H), 0,
                                                        pr.dH ? (int)((uint32_t)M * FF * 2) : 0, 0x00020000);
@@ -120,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int NIMG = 3;
+  constexpr int NIMG = SIGNS ? 2 : 3;
   const int TOTAL = (c1 - c0) * NIMG;
   const bool wdma = NW == S::NWD || wave < S::NWD;   // this wave issues weight-image DMA
   uint32_t offA[WD], offB[WD], offH[HD];
@@ -152,6 +242,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   // WD = HD instructions on a wave that issues weight images).  A wave that only brings in hidden-activation rows
   // has, behind such an image, just the stores of the previous mask step.
   auto wait_image = [&](int i, int ph) {
+    if constexpr (SIGNS) {   // weight images only: two younger ones in flight
+      if (!wdma) return;
+      if (i + 2 < TOTAL) {
+        if (WD == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if (i + 1 < TOTAL) {
+        if (WD == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      return;
+    }
     if (!wdma) {
       if (ph == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       return;
@@ -170,8 +273,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   const float dscale = pr.drop_p > 0.f ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
 
   issue(c0, 0, 0);
-  issue(c0, 1, 1);
-  issue(c0, 2, 2);
+  if constexpr (SIGNS) {
+    issue(c0, 2, 1);
+    issue(c0 + 1, 0, 2);
+  } else {
+    issue(c0, 1, 1);
+    issue(c0, 2, 2);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counted waits below assume a full pipeline behind them
 
   for (int c = c0; c < c1; ++c) {
@@ -184,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
     {
       wait_image(i, 0);
       __builtin_amdgcn_s_barrier();
-      if (i + AHEAD < TOTAL) issue(c + 1, 0, i + AHEAD);
+      if (i + AHEAD < TOTAL) issue(c + 1, SIGNS ? 2 : 0, i + AHEAD);
       const unsigned char* img = smem + (i & (NSLOT - 1)) * RSLOT;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -200,7 +308,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
       ++i;
     }
     bf16x8 hf[MT][2];
-    {
+    if constexpr (SIGNS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t mw = mk[mt][0] << (8 * (c & 1));   // the flags of an odd chunk sit 8 bits below those of an even one
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gv = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
+            o[e] = (bf16)((mw & (1u << sign_bit(0, tp, e))) ? gv * dscale : 0.f);
+          }
+          hf[mt][tp] = o;
+        }
+        if (c & 1) {
+#pragma unroll
+          for (int j = 0; j < 15; ++j) mk[mt][j] = mk[mt][j + 1];
+        }
+      }
+    } else {
       wait_image(i, 1);
       __builtin_amdgcn_s_barrier();
       if (i + AHEAD < TOTAL) issue(c + 1, 1, i + AHEAD);
@@ -225,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
     {
       wait_image(i, 2);
       __builtin_amdgcn_s_barrier();
-      if (i + AHEAD < TOTAL) issue(c + 1, 2, i + AHEAD);
+      if (i + AHEAD < TOTAL) issue(SIGNS ? c + 2 : c + 1, SIGNS ? 0 : 2, i + AHEAD);
       const unsigned char* img = smem + (i & (NSLOT - 1)) * RSLOT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -244,71 +371,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   if constexpr (SPLIT) {   // partial sums; the row epilogue runs as a second launch over all slabs
     store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
   } else {
-    __syncthreads();  // the ring doubles as the column-sum scratch of the LayerNorm backward
-    if (pr.Wn == nullptr) {
-      epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
-      return;
-    }
-    // Chained GEMM behind the epilogue: Cn = E Wn with E = the rows the epilogue has just produced (the gradient
-    // through the linear layer in front of the block), so those rows are not re-read by a separate launch.  Wn
-    // [k][j] arrives by LDS-DMA as two contraction-major images (k 0..63, 64..127) in the upper half of the ring while
-    // the epilogue runs (its scratch is the first NW KiB); E stays in registers as MFMA fragments.
-    unsigned char* wimg = smem + 2 * RSLOT;
-    {
-      constexpr int PER = 32 / (NW < 8 ? NW : 8);   // 32 instructions of 4 rows x 256 B over the first 8 waves
-      if (wave < 8) {
+    bwd_rows_epilogue<NW>(acc, pr, p0, pw0, lane, wave, tid, smem, smem + 2 * RSLOT);
+  }
+}
+
+// Sign words from a stored hidden activation, for the forward paths that do not produce them in the kernel (hidden
+// split, two-GEMM form): one thread per word.
+__global__ __launch_bounds__(256) void ffn_signs_kernel(const FfnBatch batch) {
+  for (int gi = 0; gi < batch.n; ++gi) {
+    const FfnProb& pr = batch.p[gi];
+    if (!pr.Hs) continue;
+    const long words = (long)pr.epi.Pn * 64;
+    for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long)gridDim.x * 256) {
+      const long m = w >> 6;
+      const int qq = (int)(w >> 4) & 3, j = (int)w & 15;
+      uint32_t bits = 0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-          const int piece = wave * PER + j, row = piece * 4 + (lane >> 4), s = lane & 15;
-          const int ch = (((s >> 1) ^ fsw(row & 63)) << 1) | (s & 1);   // logical 16-byte chunk that lands at position s
-          glds16(pr.Wn + row * DM + ch * 8, wimg + piece * 1024);
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pr.H + m * FF + (2 * j + cc) * HC + tp * 32 + 8 * qq);
+          const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t hv = (d[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+            if (hv != 0 && !(hv & 0x8000u)) bits |= 1u << sign_bit(cc, tp, e);
+          }
         }
-      }
-    }
-    epi_lnbwd<NW>(acc, pr.epi, p0, pw0, lane, wave, tid, smem);
-    // E as MFMA fragments: every lane reads back the 16-byte pieces it has just stored (its own writes, L2 hits);
-    // holding them in registers across the epilogue instead costs 32 registers there and 64 spilled ones
-    const bf16* E = pr.epi.C2 ? pr.epi.C2 : (const bf16*)pr.epi.C;
-    const int lde = pr.epi.C2 ? DM : pr.epi.ldc;
-    bf16x8 keep[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = p0 + pw0 + mt * 16 + (lane & 15);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < M) v = *reinterpret_cast<const uint4*>(E + (size_t)m * lde + ks * 32 + 8 * q);
-        keep[mt][ks] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const unsigned char* img = wimg + (ks >> 1) * SLOT;
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const bf16x8 wf = frag_t(img, (nt >> 1) * 32 + 8 * (lane & 3) + 4 * (nt & 1), ks & 1, lane);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, keep[mt][ks], acc[mt][nt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = p0 + pw0 + mt * 16 + (lane & 15);
-      if (m >= M) continue;
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[mt][2 * tp][e]; v[4 + e] = acc[mt][2 * tp + 1][e]; }
-        store8(pr.Cn + (size_t)m * DM + tp * 32 + 8 * q, v);
-      }
+      pr.Hs[w] = bits;
     }
   }
 }
@@ -319,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
 //   second GEMM of chunk c-1         (MFMA, image W2(c-1), operand = bf16 hidden fragments of the previous step)
 //   bias/ReLU/dropout of chunk c     (VALU, fills the MFMA shadow) -> store + fragments for the next step
 // LDS: two slots per weight (the image being read, the image in flight), filled right after the barrier.
-template <bool DROP, int NW>
+template <bool DROP, int NW, bool SIGNS>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const FfnBatch batch) {
   typedef Shape<NW> S;
   constexpr int MT = S::MT, WD = S::WD;
@@ -362,6 +452,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
     *reinterpret_cast<f32x4*>(b1s + i * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + i * 4) * dscale;
   // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
   const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
+  // sign words of the hidden activation (see FfnProb::Hs): the 16 flags of a chunk are gathered with three operations
+  // per pair of entries, two chunks make a word, and four words go out as one 16-byte store every 8 chunks; zero
+  // records = every store dropped
+  const auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(pr.Hs ? (void*)pr.Hs : (void*)pr.H), 0,
+                                                       pr.Hs ? (int)((uint32_t)M * 256) : 0, 0x00020000);
+  uint32_t fm[MT][4], fcur[MT], soff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    soff[mt] = (uint32_t)(p0 + pw0 + mt * 16 + (lane & 15)) * 256 + q * 64;
+    fcur[mt] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fm[mt][j] = 0;
+  }
 
   f32x4 acc[MT][8];
 #pragma unroll
@@ -395,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
 
   f32x4 a1[MT][4];
   bf16x8 hfp[MT][2];
-  auto gemm1 = [&](int c) {
+  auto gemm1 = [&](int c) __attribute__((always_inline)) {
     const unsigned char* img = w1s + (c & 1) * SLOT;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -417,13 +520,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   // out MT at a time, each group followed by one 2-column piece of the bias/ReLU/dropout/convert work (8 MT pieces
   // over 16 slots), so the vector ALU runs in the shadow of the matrix pipe.  has2 / hasc are compile-time (the region
   // stays free of branches): whether there is a second GEMM (chunk c2) / hidden-chunk arithmetic (chunk c).
-  auto gemm2_hidden = [&](auto has2_, auto hasc_, int c2, int c) {
+  auto gemm2_hidden = [&](auto has2_, auto hasc_, int c2, int c) __attribute__((always_inline)) {
     constexpr bool has2 = decltype(has2_)::value, hasc = decltype(hasc_)::value;
     const unsigned char* img = w2s + (c2 & 1) * SLOT;
     const uint32_t chunk_pt = (uint32_t)(c * (HC / 2)) * ATTN_PAIR_MUL;
     bf16x8 qf[2][4];
     float bv[2][8];
-    uint32_t hn[MT][2][4];
+    uint32_t hn[MT][2][4], nb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) nb[mt] = 0;
     if constexpr (has2) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) qf[0][nt] = frag_n<true>(img, qrow(nt), 0, lane);
@@ -462,10 +567,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
             v0 = ((hb & 0xFFFFu) >= thr) ? v0 : 0.f;
             v1 = ((hb >> 16) >= thr) ? v1 : 0.f;
           }
-          bf16x2 o2;
-          o2[0] = (bf16)v0;
-          o2[1] = (bf16)v1;
-          hn[mt][tp][e >> 1] = __builtin_bit_cast(uint32_t, o2);
+          const f32x2 v2 = {v0, v1};
+          const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2));   // one packed convert
+          hn[mt][tp][e >> 1] = pk;
+          if constexpr (SIGNS) {
+            // both halves are bf16 values >= 0: adding 0x7FFF carries into bit 15 / 31 exactly when a half is not zero
+            const uint32_t t = pk + 0x7FFF7FFFu;
+            const int i = tp_e_index(tp, e);   // a constant once the region is unrolled
+            nb[mt] = (__builtin_amdgcn_alignbit(t, t, i) & (0x80008000u >> i)) | nb[mt];
+          }
           if ((piece & 3) == 3) {
             u32x4 o = {hn[mt][tp][0], hn[mt][tp][1], hn[mt][tp][2], hn[mt][tp][3]};
             __builtin_amdgcn_raw_buffer_store_b128(o, hrsrc, (int)(hoff[mt] + (uint32_t)(c * HC + tp * 32) * 2), 0, 0);
@@ -482,6 +592,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
           u32x4 o = {hn[mt][tp][0], hn[mt][tp][1], hn[mt][tp][2], hn[mt][tp][3]};
           hfp[mt][tp] = __builtin_bit_cast(bf16x8, o);
         }
+      if constexpr (SIGNS) {
+        if ((c & 1) == 0) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) fcur[mt] = nb[mt];
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            fm[mt][0] = fm[mt][1]; fm[mt][1] = fm[mt][2]; fm[mt][2] = fm[mt][3];
+            fm[mt][3] = fcur[mt] | (nb[mt] >> 8);
+          }
+          if ((c & 7) == 7) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              u32x4 o = {fm[mt][0], fm[mt][1], fm[mt][2], fm[mt][3]};
+              __builtin_amdgcn_raw_buffer_store_b128(o, srsrc, (int)(soff[mt] + (uint32_t)(c >> 3) * 16), 0, 0);
+            }
+          }
+        }
+      }
     }
   };
   constexpr std::true_type yes{};
@@ -498,12 +627,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   gemm1(c0);
   gemm2_hidden(no, yes, -1, c0);
 
-  auto wait_images = [&]() {   // everything older than the 2 MT hidden-activation stores of the previous step
+  // everything older than the 2 MT hidden-activation stores of the previous step (the MT sign-word stores that follow
+  // them every eighth step make this wait stricter than needed there, never weaker)
+  auto wait_images = [&]() {
     if (MT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
   // last_ (compile-time): the final chunk, no further first-GEMM image to request
-  auto step = [&](auto last_, int c) {
+  auto step = [&](auto last_, int c) __attribute__((always_inline)) {
     wait_images();   // both images of this step have landed
     __builtin_amdgcn_s_barrier();
     if constexpr (!decltype(last_)::value) issue_w1(c + 1);
@@ -682,14 +813,31 @@ int pick_waves(const FfnBatch& b, bool bwd) {
 }
 
 template <int NW>
-void launch_fwd_shape(const FfnBatch& b, int total, bool drop, hipStream_t stream) {
-  if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
-  else hipLaunchKernelGGL((ffn_fwd_kernel<false, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+void launch_fwd_shape(const FfnBatch& b, int total, bool drop, bool signs, hipStream_t stream) {
+  if (signs) {
+    if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true, NW, true>), dim3(total), dim3(NW * 64), 0, stream, b);
+    else hipLaunchKernelGGL((ffn_fwd_kernel<false, NW, true>), dim3(total), dim3(NW * 64), 0, stream, b);
+  } else {
+    if (drop) hipLaunchKernelGGL((ffn_fwd_kernel<true, NW, false>), dim3(total), dim3(NW * 64), 0, stream, b);
+    else hipLaunchKernelGGL((ffn_fwd_kernel<false, NW, false>), dim3(total), dim3(NW * 64), 0, stream, b);
+  }
 }
 template <int NW>
-void launch_bwd_shape(const FfnBatch& b, int total, bool split, hipStream_t stream) {
+void launch_bwd_shape(const FfnBatch& b, int total, bool split, bool signs, hipStream_t stream) {
   if (split) hipLaunchKernelGGL((ffn_bwd_kernel<true, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+  else if (signs) hipLaunchKernelGGL((ffn_bwd_kernel<false, NW, true>), dim3(total), dim3(NW * 64), 0, stream, b);
   else hipLaunchKernelGGL((ffn_bwd_kernel<false, NW>), dim3(total), dim3(NW * 64), 0, stream, b);
+}
+// sign words for the forward paths whose kernels do not write them
+int signs_from_hidden(const FfnBatch& b, hipStream_t stream) {
+  long words = 0;
+  for (int i = 0; i < b.n; ++i)
+    if (b.p[i].Hs) words += (long)b.p[i].epi.Pn * 64;
+  if (words == 0) return MMST_OK;
+  const long blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(ffn_signs_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, b);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
 }
 
 }  // namespace
@@ -700,14 +848,22 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   int total = prepare(b, false, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
-  if (!split && total < fuse_min_tiles()) return ffn_fwd_unfused(b, stream);
+  if (!split && total < fuse_min_tiles()) {
+    const int rc = ffn_fwd_unfused(b, stream);
+    return rc ? rc : signs_from_hidden(b, stream);
+  }
   bool drop = false;
   for (int i = 0; i < b.n; ++i) drop = drop || b.p[i].drop_p > 0.f;
-  if (nw == 4) launch_fwd_shape<4>(b, total, drop, stream);
-  else if (nw == 8) launch_fwd_shape<8>(b, total, drop, stream);
-  else launch_fwd_shape<10>(b, total, drop, stream);
+  bool signs = false;   // written in the kernel only by workgroups that walk the whole hidden dimension
+  for (int i = 0; i < b.n; ++i) signs = signs || (b.p[i].Hs != nullptr && !split);
+  if (nw == 4) launch_fwd_shape<4>(b, total, drop, signs, stream);
+  else if (nw == 8) launch_fwd_shape<8>(b, total, drop, signs, stream);
+  else launch_fwd_shape<10>(b, total, drop, signs, stream);
   MMST_CHECK_LAUNCH();
-  if (split) return row_epilogue(b, false, stream);
+  if (split) {   // the kernel's sign-word stores assume a workgroup that walks the whole hidden dimension
+    const int rc = signs_from_hidden(b, stream);
+    return rc ? rc : row_epilogue(b, false, stream);
+  }
   return MMST_OK;
 }
 
@@ -727,27 +883,35 @@ int launch_ffn_bwd(FfnBatch& b, hipStream_t stream, bool* next_done) {
   if (split || !chained)   // the chained GEMM is all problems or none, and lives in the kernel without hidden split
     for (int i = 0; i < b.n; ++i) b.p[i].Wn = nullptr;
   else if (next_done) *next_done = true;
-  if (nw == 4) launch_bwd_shape<4>(b, total, split, stream);
-  else if (nw == 8) launch_bwd_shape<8>(b, total, split, stream);
-  else launch_bwd_shape<10>(b, total, split, stream);
+  // sign words for every problem and no stored hidden gradient: the kernel that never reads the hidden activation
+  bool signs = true;
+  for (int i = 0; i < b.n; ++i) signs = signs && b.p[i].Hs != nullptr && b.p[i].dH == nullptr;
+  if (nw == 4) launch_bwd_shape<4>(b, total, split, signs, stream);
+  else if (nw == 8) launch_bwd_shape<8>(b, total, split, signs, stream);
+  else launch_bwd_shape<10>(b, total, split, signs, stream);
   MMST_CHECK_LAUNCH();
   if (split) return row_epilogue(b, true, stream);
   return MMST_OK;
 }
 
-// Weight gradients of fused launches: 1 (default) or 2 = ffn_wgrad.hip recomputes the hidden gradient, which is then
+// Weight gradients of fused launches: 1 (default), 2 or 3 = ffn_wgrad.hip recomputes the hidden gradient, which is then
 // never written or re-read as a [rows][2048] matrix (2.3 GB less HBM traffic per training step at 64 molecules, the
-// backward kernel 45 us shorter per layer), with its 4-wave (1) or 8-wave (2) shape; 0 = the backward kernel stores it
-// and the grouped split-K GEMM consumes it.  Environment: MMST_FFN_WGRAD_RECOMPUTE.
+// backward kernel 45 us shorter per layer), with its 4-wave (1, 3) or 8-wave (2) shape; 0 = the backward kernel stores
+// it and the grouped split-K GEMM consumes it.  3 = as 1, and the layer entry points also pass the sign words of the
+// hidden activation (FfnProb::Hs) from the forward to the backward launch, which then does not read the hidden
+// activation at all: another 2.4 GB less traffic per step, but 0.03 ms more time (the forward kernel is bound by its
+// vector instructions and gathering the flags costs 5 us per launch, the backward kernel gains 4 us).
+// Environment: MMST_FFN_WGRAD_RECOMPUTE.
 int g_wgrad_recompute = -1;
 int ffn_wgrad_recompute() {
   if (g_wgrad_recompute < 0) {
     const char* e = getenv("MMST_FFN_WGRAD_RECOMPUTE");
     const int v = e ? atoi(e) : 1;
-    g_wgrad_recompute = (v >= 0 && v <= 2) ? v : 1;
+    g_wgrad_recompute = (v >= 0 && v <= 3) ? v : 1;
   }
   return g_wgrad_recompute;
 }
-void ffn_set_wgrad_recompute(int on) { g_wgrad_recompute = on < 0 ? -1 : (on > 2 ? 1 : on); }   // negative: back to the default
+void ffn_set_wgrad_recompute(int on) { g_wgrad_recompute = on < 0 ? -1 : (on > 3 ? 1 : on); }   // negative: back to the default
+bool ffn_bwd_signs() { return ffn_wgrad_recompute() == 3; }
 void ffn_set_fuse_min_tiles(int tiles) { g_fuse_min_tiles = tiles; }
 int ffn_fuse_min_tiles() { return fuse_min_tiles(); }

@@ -181,6 +181,7 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
     FfnProb f = ffn_fwd_prob(a[i].x1, a[i].B * a[i].S, p[i].w_1, p[i].b_1, p[i].w_2, p[i].b_2, p[i].g2, p[i].be2, a[i].h,
                              a[i].z2, a[i].st2, a[i].y, drop_p, seed + 8 * i + 2, seed + 8 * i + 3);
     if (a[i].y_L > 0) { f.epi.cS = a[i].S; f.epi.cL = a[i].y_L; f.epi.coff = a[i].y_off; }
+    f.Hs = ffn_bwd_signs() ? (uint32_t*)a[i].hsign : nullptr;
     fb.p[i] = f;
   }
   RUN(launch_ffn_fwd(fb, st));
@@ -217,6 +218,7 @@ int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const 
     q.dgamma = g[i].g1; q.dbeta = g[i].be1;
     q.drop_p = drop_p; q.seed = seed + 8 * i + 1;
     f.Wn = (const bf16*)p[i].w_o; f.Cn = (bf16*)w[i].da;
+    f.Hs = ffn_bwd_signs() ? (uint32_t*)a[i].hsign : nullptr;
     fb.p[i] = f;
   }
   return launch_ffn_bwd(fb, st, da_done);

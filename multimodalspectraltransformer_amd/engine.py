@@ -297,7 +297,7 @@ class Plan:
         def enc_acts(M, Hh, S_):
             return dict(qkv=cv.take(M * 3 * D), attn=cv.take(M * D), lse=cv.take(B * Hh * S_, f32), z1=cv.take(M * D),
                         st1=cv.take(M * 2, f32), x1=cv.take(M * D), h=cv.take(M * FF), z2=cv.take(M * D),
-                        st2=cv.take(M * 2, f32), y=cv.take(M * D))
+                        st2=cv.take(M * 2, f32), y=cv.take(M * D), hsign=cv.take(M * 64, f32))
 
         self.modal_acts = [[enc_acts(B * S, 16, S) for _, S, _ in self.mods] for _ in range(nl)]
         self.cross_acts = [enc_acts(B * Lm, 4, Lm) for _ in range(nl)]
@@ -404,7 +404,7 @@ class Plan:
                 a.y = _P(self.mem_in) if last else _P(acts["y"])
                 a.y_L, a.y_off = (Lm, off) if last else (0, 0)
                 a.kbias = _P(self.kbias[name])
-                for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
+                for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2", "hsign"):
                     setattr(a, f, _P(acts[f]))
                 a.B, a.S = B, S
                 w, sc = W_[i], self.modal_bwd[l][i]
@@ -432,7 +432,7 @@ class Plan:
             a.x = _P(self.mem_in) if l == 0 else _P(self.cross_acts[l - 1]["y"])
             a.y = _P(acts["y"])
             a.kbias = _P(self.kbias_glob)
-            for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2"):
+            for f in ("qkv", "attn", "lse", "z1", "st1", "x1", "h", "z2", "st2", "hsign"):
                 setattr(a, f, _P(acts[f]))
             a.B, a.S = B, Lm
             w, sc = W_[0], self.cross_bwd[l]

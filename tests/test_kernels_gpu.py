@@ -214,7 +214,7 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
         pytest.skip("large case exercises the fused kernels only")
     L.check(L.lib().mmst_ffn_config(0 if fused else 1 << 20), "cfg")
     try:
-        fw, bw, keepers = [], [], []
+        fw, bw, keepers, bw2, outs2 = [], [], [], [], []
         for gi in range(groups):
             Mg = M + 17 * gi
             sd = 10 * gi
@@ -227,7 +227,8 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
             z = torch.empty_like(y)
             st = torch.empty(Mg, 2, device=DEV)
             ws = torch.full((8, Mg, 128), float("nan"), device=DEV) if fused == "split" else None
-            fw.append(dict(X=x, W1=w1, W2=w2, b1=b1, H=h, ws=ws, drop_p=p, seed=100 + gi,
+            hs = torch.full((Mg, 64), 0x5A5A5A5A, dtype=torch.int32, device=DEV)   # sign words of h, every one to be written
+            fw.append(dict(X=x, W1=w1, W2=w2, b1=b1, H=h, Hs=hs, ws=ws, drop_p=p, seed=100 + gi,
                            epi=dict(Pn=Mg, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st,
                                     drop_p=p, seed=200 + gi)))
             dzd, dz = bf(rnd(Mg, 128, seed=sd + 8)), bf(rnd(Mg, 128, seed=sd + 9))
@@ -243,10 +244,37 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
                            epi=dict(Pn=Mg, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, dgamma=dg, dbeta=db,
                                     C2=dzd1, drop_p=p, seed=300 + gi)))
             keepers.append((x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db, dzd1, wn, cn))
+            # the same backward from the sign words alone (no stored hidden gradient): h is poisoned before it runs
+            o2 = dict(dz1=torch.empty_like(y), dzd1=torch.empty_like(y) if p > 0 else None, cn=torch.empty_like(cn),
+                      dg=torch.zeros(128, device=DEV), db=torch.zeros(128, device=DEV))
+            bw2.append(dict(bw[-1], H=h, Hs=hs, dH=None if fused is True else torch.empty_like(h), Cn=o2["cn"],
+                            epi=dict(bw[-1]["epi"], C=o2["dz1"], C2=o2["dzd1"], dgamma=o2["dg"], dbeta=o2["db"])))
+            outs2.append((hs, o2))
         ops.ffn_launch(ops.ffn_batch(fw), backward=False)
         chained = ops.ffn_launch(ops.ffn_batch(bw), backward=True)
         assert chained == (1 if fused is True else 0)
         torch.cuda.synchronize()
+        hidden = [k[7].clone() for k in keepers]
+        if fused is True:
+            for k in keepers:
+                k[7].fill_(float("nan"))
+        assert ops.ffn_launch(ops.ffn_batch(bw2), backward=True) == chained
+        torch.cuda.synchronize()
+        for k, hc in zip(keepers, hidden):
+            k[7].copy_(hc)
+        for (hs, o2), k in zip(outs2, keepers):
+            h, dz1, dg, db, dzd1, cn = k[7], k[12], k[14], k[15], k[16], k[18]
+            # word 16 q + j  <->  columns 64 c + 32 t + 8 q + e (c = 2 j + odd); flag bit (e odd ? 31 : 15) - 4 t - (e >> 1) - 8 odd
+            pos = (h.float() > 0).view(-1, 16, 2, 2, 4, 8).permute(0, 4, 1, 2, 3, 5).reshape(-1, 64, 2, 2, 8).long()
+            bit = torch.tensor([[[(31 if e & 1 else 15) - 4 * t - (e >> 1) - 8 * odd for e in range(8)] for t in range(2)]
+                                for odd in range(2)], device=DEV)
+            words = (pos << bit).sum((-1, -2, -3))
+            assert torch.equal(hs.long() & 0xFFFFFFFF, words)
+            assert torch.equal(o2["dz1"], dz1)
+            close(o2["dg"], dg, rtol=1e-5, atol=1e-5)   # column sums by atomics: the order differs from run to run
+            close(o2["db"], db, rtol=1e-5, atol=1e-5)
+            assert dzd1 is None or torch.equal(o2["dzd1"], dzd1)
+            assert not chained or torch.equal(o2["cn"], cn)
         for gi, (x, w1, w2, b1, b2, gam, bet, h, y, z, dzd, dz, dz1, dh, dg, db, dzd1, wn, cn) in enumerate(keepers):
             Mg = x.shape[0]
             pre = torch.relu(x.float() @ w1.float().t() + b1)
@@ -291,9 +319,9 @@ def test_ffn_fwd_bwd(fused, M, groups, p):
         L.check(L.lib().mmst_ffn_config(-1), "cfg")
 
 
-@pytest.fixture(params=[1, 2])
+@pytest.fixture(params=[1, 2, 3])
 def wgrad_shape(request):
-    """Both workgroup shapes of the recomputing kernel: setting 1 (4 waves) and 2 (8 waves)."""
+    """Both workgroup shapes of the recomputing kernel: setting 1 (4 waves; 3 is the same kernel) and 2 (8 waves)."""
     L.check(L.lib().mmst_ffn_wgrad_config(request.param), "mmst_ffn_wgrad_config")
     assert L.lib().mmst_ffn_wgrad_mode() == request.param
     yield request.param

@@ -19,13 +19,14 @@ for M in Ms:
     h = torch.empty(M, 2048, device=dev, dtype=torch.bfloat16); z = torch.empty(M, 128, device=dev, dtype=torch.bfloat16)
     y = torch.empty_like(z); st = torch.empty(M, 2, device=dev)
     ws = torch.empty(8, M, 128, device=dev) if os.environ.get('FFN_WS') else None
-    fb = ops.ffn_batch([dict(X=x, W1=w1, W2=w2, b1=b1, H=h, ws=ws, drop_p=DP, seed=7,
+    hs = torch.zeros(M, 64, device=dev, dtype=torch.int32) if os.environ.get('FFN_SIGNS') else None   # needs FFN_NODH
+    fb = ops.ffn_batch([dict(X=x, W1=w1, W2=w2, b1=b1, H=h, Hs=hs, ws=ws, drop_p=DP, seed=7,
                              epi=dict(Pn=M, C=y, ldc=128, bias=b2, R=x, ldr=128, gamma=gam, beta=bet, Z=z, stats=st, drop_p=DP, seed=9))])
     dzd = r(M, 128).bfloat16(); dz = r(M, 128).bfloat16(); dz1 = torch.empty_like(z); dzd1 = torch.empty_like(z)
     dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev)
     w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
     dh = torch.empty_like(h)
-    bb = ops.ffn_batch([dict(X=dzd, W1=w2t, W2=w1t, H=h, dH=None if os.environ.get('FFN_NODH') else dh, ws=ws, drop_p=0.1,
+    bb = ops.ffn_batch([dict(X=dzd, W1=w2t, W2=w1t, H=h, Hs=hs, dH=None if os.environ.get('FFN_NODH') else dh, ws=ws, drop_p=0.1,
                              epi=dict(Pn=M, C=dz1, ldc=128, R=dz, ldr=128, gamma=gam, Z=z, stats=st, C2=dzd1, dgamma=dg, dbeta=db, drop_p=0.1, seed=5))])
     for name, b, bwd in (("fwd", fb, False), ("bwd", bb, True)):
         for _ in range(3): ops.ffn_launch(b, bwd)
