@@ -76,6 +76,14 @@ int mmst_ffn_wgrad_config(int recompute) {
 
 int mmst_ffn_wgrad_mode(void) { return ffn_wgrad_recompute(); }
 
+// attention backward of non-causal self-attention in one pass: bit 0 = head_dim 32, bit 1 = head_dim 8; 0 = the two
+// passes (dQ, then dK/dV) everywhere; negative: the default (1, or what MMST_ATTN_BWD_MERGED says)
+int mmst_attn_bwd_config(int mode) {
+  attn_set_bwd_merged(mode);
+  return MMST_OK;
+}
+int mmst_attn_bwd_mode(void) { return attn_bwd_merged(); }
+
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
 int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {
   GemmTap& t = g_gemm_tap;

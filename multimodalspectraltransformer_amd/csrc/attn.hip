@@ -259,7 +259,8 @@ __device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& 
   }
 }
 
-// dK and dV rows of key `key` of head hh: a lane per query
+// dK and dV rows of key `key` of head hh: a lane per query (INLINE_DELTA: delta = dO . O computed here instead of read)
+template <bool INLINE_DELTA = false>
 __device__ __forceinline__ void kv_owner_tail(const AttnProb& pr, const TailCtx& tc, int b, int hh, int key, int lane) {
   constexpr int HD = 8;
   const int H = pr.H, Tq = pr.Tq, Sk = pr.Sk;
@@ -280,7 +281,8 @@ __device__ __forceinline__ void kv_owner_tail(const AttnProb& pr, const TailCtx&
       dp = keep ? dp * tc.dscale : 0.f;
       pk = keep ? p * tc.dscale : 0.f;
     }
-    const float ds = p * (dp - pr.delta[stat]) * tc.scale;
+    const float dlt = INLINE_DELTA ? dot8(dorow, ldrow8(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD)) : pr.delta[stat];
+    const float ds = p * (dp - dlt) * tc.scale;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
       dv[d] += pk * (float)dorow[d];
@@ -661,6 +663,327 @@ __global__ void attn_kv_kernel(const AttnBatch batch) {
   store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Single-pass backward of self-attention without a causal mask (the encoder layers): dQ, dK and dV from ONE
+// evaluation of the probabilities (the two-pass form above evaluates exp, the dropout hash and dS twice).
+// A workgroup owns one batch element and ALL rows of a column group (one head of 32 with ten waves, or 8 heads of 8
+// with two waves per head).  A wave owns 32-key tiles (kt = pass * WPH + part) exactly as in the dK/dV pass: S and dP
+// with the key on the lane, dK and dV in accumulators.  All waves walk the query tiles in step.  dS is transposed
+// through an LDS region of the wave (16 two-byte writes, two 16-byte reads per tile) and multiplied with the tile's
+// K^T fragments, held in registers, to the wave's contribution to dQ of that query tile.  The contributions of a
+// head's waves are summed through LDS without atomics (LDS float atomics run at about 0.4 lanes per clock and CU):
+// each wave stores its 32 x HD partial into the region (double-buffered by step parity), one barrier, and a fixed
+// thread per 16-byte piece adds the partials into the fp32 dQ rows of the current 128-query chunk, which go out as
+// bf16 when the chunk is left (added to the first pass's value when a second pass over the key tiles revisits the
+// chunk).  Nothing of dQ is reduced through HBM.  delta = dO . O is computed while a chunk is staged.
+// ------------------------------------------------------------------------------------------
+template <int HD> struct MCfg {
+  static constexpr int GCM = HD == 32 ? 32 : 64;    // columns per workgroup
+  static constexpr int HG = GCM / HD;               // heads per workgroup
+  static constexpr int NW = HD == 32 ? 12 : 8;      // waves
+  static constexpr int WPH = NW / HG;               // waves per head
+  static constexpr int KS = HD == 32 ? 2 : 1;
+  static constexpr int RM_BYTES = KC * GCM * 2;
+  static constexpr int TR_BYTES = GCM * TSTR;
+  static constexpr int MAXQ = HD == 32 ? 608 : 128; // most tiled rows
+  static constexpr int SSTR = 80;                   // bytes per row of the dS^T image
+  static constexpr int SLS = (HD + 4) * 4;          // bytes per row of a dQ partial
+  static constexpr int REG = 32 * (SSTR > SLS ? SSTR : SLS);   // a wave's region: dS^T image, then its dQ partial
+  static constexpr int NPOS = HG * 32 * HD / 4;     // 16-byte pieces of a query tile's dQ over the workgroup's heads
+  static constexpr int SMEM = 2 * RM_BYTES + 2 * TR_BYTES + 3 * HG * KC * 4 + 2 * NW * REG + HG * KC * HD * 4;
+};
+
+template <int GCM> __device__ __forceinline__ int rmo(int row, int ch) {
+  if (GCM == 64) return rm_off(row, ch);
+  return row * 64 + ((ch ^ ((row >> 1) & 3)) << 4);   // 64-byte rows
+}
+template <int GCM>
+__device__ __forceinline__ void stage_m(unsigned char* rm, unsigned char* tr, const bf16* src, int ld, int nvalid,
+                                        int tid, int nthr) {
+  constexpr int CPR = GCM / 8;
+  for (int c = tid; c < KC * CPR; c += nthr) {
+    const int row = c / CPR, ch = c % CPR;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nvalid) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+    *reinterpret_cast<uint4*>(rm + rmo<GCM>(row, ch)) = v;
+    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned short*>(tr + (ch * 8 + j) * TSTR + row * 2) = e[j];
+  }
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 afrag_m(const unsigned char* img, int row, int s, int h, int hoff) {
+  if (HD == 32) return *reinterpret_cast<const bf16x8*>(img + rmo<32>(row, 2 * s + h));
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(img + rm_off(row, hoff >> 3));
+  return h == 0 ? v : zero8();
+}
+template <int HD> __device__ __forceinline__ float row_delta(const AttnProb& pr, size_t row, int hh) {
+  const bf16* dor = pr.dO + row * pr.lddo + hh * HD;
+  const bf16* orow = pr.O + row * pr.ldo + hh * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 8; ++c) s += dot8(ldrow8(dor + 8 * c), ldrow8(orow + 8 * c));
+  return s;
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(MCfg<HD>::NW * 64, 1) void attn_bwd_kernel(const AttnBatch batch) {
+  typedef MCfg<HD> C;
+  constexpr int NW = C::NW, HG = C::HG, WPH = C::WPH, KS = C::KS, GCM = C::GCM, NTHR = NW * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = Qimg + C::RM_BYTES;
+  unsigned char* Qt = Dimg + C::RM_BYTES;
+  unsigned char* Dt = Qt + C::TR_BYTES;
+  float* lse_all = reinterpret_cast<float*>(Dt + C::TR_BYTES);   // [HG][KC]
+  float* del_all = lse_all + HG * KC;
+  uint32_t* rs_all = reinterpret_cast<uint32_t*>(del_all + HG * KC);
+  unsigned char* reg_all = reinterpret_cast<unsigned char*>(rs_all + HG * KC);   // [2][NW][REG]
+  float* dqc = reinterpret_cast<float*>(reg_all + 2 * NW * C::REG);              // [HG][KC][HD]
+
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < ATTN_MAX_GROUPS; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.p[i].block_begin) g = i;
+  const AttnProb& pr = batch.p[g];
+  const int local = (int)blockIdx.x - pr.block_begin;
+  const int ngroups = pr.H / HG;
+  const int b = local / ngroups, hg = local % ngroups;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int hl = wave % HG, part = wave / HG, hoff = hl * HD, gcol = hg * GCM;
+  const int hh = hg * HG + hl, H = pr.H, S = pr.Sk;
+  const int tail = HD == 8 ? pr.tail_o : 0;
+  const int S_main = S - tail;
+  const float* lse_s = lse_all + hl * KC;
+  const float* del_s = del_all + hl * KC;
+  const uint32_t* rs_s = rs_all + hl * KC;
+  const float scale = rsqrtf((float)HD);
+  const float scale2 = scale * LOG2E;
+  const uint32_t thr = drop_threshold(batch.drop_p);
+  const float dscale = DROP ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
+  const float inv_dscale = DROP ? 1.0f - batch.drop_p : 1.0f;
+  constexpr bool dropping = DROP;
+  // The tile arithmetic leaves the constant factors out: dS' = P (keep dP - delta / dscale), P' = keep P; the sums are
+  // scaled once: dK and dQ by scale * dscale, dV by dscale.
+  const float kq_mul = scale * dscale;
+
+  const int nkt = (S_main + 31) >> 5;
+  const int npass = (nkt + WPH - 1) / WPH;
+  const bool single = S_main <= KC;   // the one chunk is staged once and serves every pass
+  const TailCtx tc = {scale, scale2, dscale, thr, dropping};
+
+  // dQ rows of chunk c0 leave the workgroup: bf16, added to what an earlier pass wrote (`add`), plus (head_dim 8,
+  // last flush) what the tail keys contribute, which no tile covers; then the chunk array is cleared
+  auto flush = [&](int c0, bool add, bool with_tails) {
+    const int nvalid = min(KC, S_main - c0);
+    constexpr int PPR = HD / 8;   // 16-byte bf16 pieces per row and head
+    for (int idx = tid; idx < HG * KC * PPR; idx += NTHR) {
+      const int hj = idx / (KC * PPR), q = (idx / PPR) % KC, c = idx % PPR;
+      float* src = dqc + (hj * KC + q) * HD + 8 * c;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = src[j] * kq_mul; src[j] = 0.f; }
+      if (q >= nvalid) continue;
+      const int head = hg * HG + hj;
+      bf16* out = pr.dQ + (size_t)(b * S + c0 + q) * pr.lddq + head * HD + 8 * c;
+      if (add) {
+        const bf16x8 old = ldrow8(out);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)old[j];
+      }
+      if (HD == 8 && with_tails && tail > 0) {
+        const int qg = c0 + q;
+        const size_t stat = (size_t)(b * H + head) * S + qg;
+        const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * S + qg) * pr.ldq + head * HD);
+        const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * S + qg) * pr.lddo + head * HD);
+        const float dlt = dot8(dorow, ldrow8(pr.O + (size_t)(b * S + qg) * pr.ldo + head * HD));
+        const float lse2 = pr.lse[stat];
+        const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)stat);
+        for (int t = 0; t < tail; ++t) {
+          const int key = S_main + t;
+          const bf16x8 kt = ldrow8(pr.K + (size_t)(b * S + key) * pr.ldk + head * HD);
+          const bf16x8 vt = ldrow8(pr.V + (size_t)(b * S + key) * pr.ldv + head * HD);
+          const float bt = pr.kbias ? pr.kbias[(size_t)b * S + key] * LOG2E : 0.f;
+          const float p = __builtin_amdgcn_exp2f(dot8(qrow, kt) * scale2 + bt - lse2);
+          float dp = dot8(dorow, vt);
+          const bool keep = !dropping || keep_of(rseed, key, thr);
+          dp = keep ? dp * dscale : 0.f;
+          const float dsv = p * (dp - dlt) * scale;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) v[d] += dsv * (float)kt[d];
+        }
+      }
+      store_row8(out, v, 1.0f);
+    }
+  };
+
+  for (int i = tid; i < HG * KC * HD; i += NTHR) dqc[i] = 0.f;
+  int step = 0;
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int kt = pass * WPH + part;
+    const bool active = kt < nkt;
+    const int nact = min(WPH, nkt - pass * WPH);   // waves per head with a key tile in this pass
+    const int k0 = kt * 32, key = k0 + r;
+    const bool kvalid = active && key < S_main;
+    const uint32_t pair_term = (uint32_t)(key >> 1) * ATTN_PAIR_MUL;
+    const uint32_t pair_shift = (key & 1) ? 16u : 0u;
+    bf16x8 kf[KS], vf[KS], ktf[2];
+    load_owner<HD>(kf, pr.K + (size_t)(b * S + (kvalid ? key : 0)) * pr.ldk + hh * HD, h, kvalid);
+    load_owner<HD>(vf, pr.V + (size_t)(b * S + (kvalid ? key : 0)) * pr.ldv + hh * HD, h, kvalid);
+    float bias2 = -INFINITY;
+    if (kvalid) bias2 = pr.kbias ? pr.kbias[(size_t)b * S + key] * LOG2E : 0.f;
+    // K^T of the tile as the A operand of dQ^T += K^T dS^T: lane (d, h) holds keys k0 + 16 s + 8 h + j
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kk = k0 + 16 * s + 8 * h + j;
+        const bool ok = active && kk < S_main && (HD == 32 || r < 8);
+        ktf[s][j] = ok ? pr.K[(size_t)(b * S + kk) * pr.ldk + hh * HD + (HD == 32 ? r : (r & 7))] : (bf16)0.f;
+      }
+    f32x16 dkacc = zero16(), dvacc = zero16();
+
+    for (int c0 = 0; c0 < S_main; c0 += KC) {
+      const int nvalid = min(KC, S_main - c0);
+      if (!(single && pass > 0)) {
+        __syncthreads();
+        if (c0 > 0) flush(c0 - KC, pass > 0, false);
+        stage_m<GCM>(Qimg, Qt, pr.Q + (size_t)(b * S + c0) * pr.ldq + gcol, pr.ldq, nvalid, tid, NTHR);
+        stage_m<GCM>(Dimg, Dt, pr.dO + (size_t)(b * S + c0) * pr.lddo + gcol, pr.lddo, nvalid, tid, NTHR);
+        for (int j = tid; j < HG * KC; j += NTHR) {
+          const int hj = j / KC, i = j % KC, head = hg * HG + hj;
+          float lv = 1.0e30f, dv = 0.f;
+          if (i < nvalid) {
+            lv = pr.lse[(size_t)(b * H + head) * S + c0 + i];
+            dv = row_delta<HD>(pr, (size_t)b * S + c0 + i, head);
+          }
+          lse_all[j] = lv;
+          del_all[j] = dv * inv_dscale;
+          if (dropping) rs_all[j] = attn_row_seed(pr.seed, (uint32_t)((b * H + head) * S + c0 + i));
+        }
+        __syncthreads();
+      }
+      const int ntile = (nvalid + 31) >> 5;
+      for (int t = 0; t < ntile; ++t, ++step) {
+        const int lq0 = t * 32;
+        unsigned char* reg = reg_all + ((step & 1) * NW + wave) * C::REG;
+        if (active) {
+          f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_m<HD>(Qimg, lq0 + r, s, h, hoff), kf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_m<HD>(Dimg, lq0 + r, s, h, hoff), vf[s], dpacc, 0, 0, 0);
+          }
+          float pd[16], ds[16];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 ll = *reinterpret_cast<const f32x4*>(lse_s + lq0 + 8 * g4 + 4 * h);
+            f32x4 dd = *reinterpret_cast<const f32x4*>(del_s + lq0 + 8 * g4 + 4 * h);
+            uint32_t rsv[4] = {0, 0, 0, 0};
+            if (dropping) {
+              const uint4 rr = *reinterpret_cast<const uint4*>(rs_s + lq0 + 8 * g4 + 4 * h);
+              rsv[0] = rr.x; rsv[1] = rr.y; rsv[2] = rr.z; rsv[3] = rr.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = 4 * g4 + j;
+              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, bias2 - ll[j]));
+              float d = dpacc[i];
+              float pk = p;
+              if (dropping) {
+                const uint32_t hb = attn_pair_bits(rsv[j], pair_term);
+                const bool keep = ((hb >> pair_shift) & 0xFFFFu) >= thr;
+                d = keep ? d : 0.f;
+                pk = keep ? p : 0.f;
+              }
+              pd[i] = pk;
+              ds[i] = p * (d - dd[j]);
+            }
+          }
+          const bf16x8 pf0 = pack8(pd), pf1 = pack8(pd + 8), sf0 = pack8(ds), sf1 = pack8(ds + 8);
+          dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 0, lane, hoff), pf0, dvacc, 0, 0, 0);
+          dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 1, lane, hoff), pf1, dvacc, 0, 0, 0);
+          dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 0, lane, hoff), sf0, dkacc, 0, 0, 0);
+          dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Qt, lq0, 1, lane, hoff), sf1, dkacc, 0, 0, 0);
+          // dS^T image: row = query of the tile, column = key of the tile
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            *reinterpret_cast<bf16*>(reg + acc_row(i, h) * C::SSTR + r * 2) = i < 8 ? sf0[i] : sf1[i - 8];
+          __builtin_amdgcn_wave_barrier();
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(reg + r * C::SSTR + 16 * h);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(reg + r * C::SSTR + 32 + 16 * h);
+          __builtin_amdgcn_wave_barrier();
+          f32x16 dqa = zero16();
+          dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0], b0, dqa, 0, 0, 0);
+          dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1], b1, dqa, 0, 0, 0);
+          // the wave's partial: row = query, 4 consecutive d per piece (the image above has been read)
+#pragma unroll
+          for (int g4 = 0; g4 < (HD == 32 ? 4 : 1); ++g4) {
+            const f32x4 o = {dqa[4 * g4], dqa[4 * g4 + 1], dqa[4 * g4 + 2], dqa[4 * g4 + 3]};
+            *reinterpret_cast<f32x4*>(reg + r * C::SLS + (8 * g4 + 4 * h) * 4) = o;
+          }
+        }
+        __syncthreads();
+        if (tid < C::NPOS) {
+          constexpr int PPH = 32 * HD / 4;   // pieces per head
+          const int hj = tid / PPH, pp = tid % PPH, q = pp / (HD / 4), f4 = pp % (HD / 4);
+          f32x4* acc = reinterpret_cast<f32x4*>(dqc + (hj * KC + lq0 + q) * HD + 4 * f4);
+          f32x4 sum = *acc;
+          for (int k = 0; k < nact; ++k)
+            sum += *reinterpret_cast<const f32x4*>(reg_all + ((step & 1) * NW + hj + HG * k) * C::REG + q * C::SLS + f4 * 16);
+          *acc = sum;
+        }
+      }
+    }
+    if (kvalid) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dkacc[i] *= kq_mul; dvacc[i] *= dscale; }
+      if (HD == 8 && tail > 0) {
+        // tail queries: one score per key lane pair (see attn_kv_kernel)
+        const bf16x8 krow = ldrow8(pr.K + (size_t)(b * S + key) * pr.ldk + hh * HD);
+        const bf16x8 vrow = ldrow8(pr.V + (size_t)(b * S + key) * pr.ldv + hh * HD);
+        for (int t = 0; t < tail; ++t) {
+          const int qt = S_main + t;
+          const size_t stat = (size_t)(b * H + hh) * S + qt;
+          const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * S + qt) * pr.ldq + hh * HD);
+          const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * S + qt) * pr.lddo + hh * HD);
+          const float dlt = dot8(dorow, ldrow8(pr.O + (size_t)(b * S + qt) * pr.ldo + hh * HD));
+          const float p = __builtin_amdgcn_exp2f(dot8(krow, qrow) * scale2 + bias2 - pr.lse[stat]);
+          float dp = dot8(vrow, dorow), pk = p;
+          if (dropping) {
+            const bool keep = keep_of(attn_row_seed(pr.seed, (uint32_t)stat), key, thr);
+            dp = keep ? dp * dscale : 0.f;
+            pk = keep ? p * dscale : 0.f;
+          }
+          const float dsv = p * (dp - dlt) * scale;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dvacc[j] += pk * (float)(h ? dorow[4 + j] : dorow[j]);
+            dkacc[j] += dsv * (float)(h ? qrow[4 + j] : qrow[j]);
+          }
+        }
+      }
+      store_rows<HD>(pr.dK + (size_t)(b * S + key) * pr.lddk + hh * HD, dkacc, 1.0f, h);
+      store_rows<HD>(pr.dV + (size_t)(b * S + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
+    }
+    if (!single || pass == npass - 1) {
+      __syncthreads();
+      flush(((S_main - 1) / KC) * KC, !single && pass > 0, true);
+    }
+  }
+
+  if (HD == 8 && tail > 0) {
+    // rows outside the tiling: the tail keys' dK/dV and the tail queries' dQ, one wave of the head each
+    if (part == 0)
+      for (int t = 0; t < tail; ++t) kv_owner_tail<true>(pr, tc, b, hh, S_main + t, lane);
+    if (part == WPH - 1)
+      for (int t = 0; t < tail; ++t) q_owner_tail<true>(pr, tc, b, hh, S_main + t, lane);
+  }
+}
+
 // rows of a side that are handled outside the MFMA tiling (see "Tail rows" above)
 int tail_of(const AttnBatch& b, int rows) {
   static const int enabled = [] { const char* e = getenv("MMST_ATTN_TAILS"); return e ? atoi(e) : 1; }();
@@ -745,9 +1068,66 @@ int launch_attn_bwd_q(AttnBatch& b, hipStream_t stream) {
   return launch_q<true>(b, stream);
 }
 
+namespace {
+// The single-pass kernel serves self-attention without a causal mask whose tiled rows fit its dQ array
+// (head_dim 8: at most 128 rows beside the tail rows; head_dim 32: at most 608).  Setting (attn_set_bwd_merged, or
+// the environment variable MMST_ATTN_BWD_MERGED): bit 0 = use it for head_dim 32, bit 1 = for head_dim 8; 0 = the
+// two-pass form everywhere.  Default 1.  Measured at 64 molecules, alone on the GPU: head_dim 32 (582 rows) 128 us
+// against 173 us for the two passes, head_dim 8 (3 x 129 + 66 rows) 111 us against 109 us (its workgroups need 150 KiB
+// of LDS for eight waves).  Inside a training step the head_dim 32 kernel is time-neutral: its 158 KiB of LDS keep
+// it off a CU while a feed-forward weight-gradient workgroup of the other stream (82 KiB) is resident, so the two
+// run one after the other where the two-pass kernels (70 KiB, 128 registers) ran beside it.
+int g_bwd_merged = -1;
+int bwd_merged_mode() {
+  if (g_bwd_merged < 0) {
+    const char* e = getenv("MMST_ATTN_BWD_MERGED");
+    const int v = e ? atoi(e) : 1;
+    g_bwd_merged = (v >= 0 && v <= 3) ? v : 1;
+  }
+  return g_bwd_merged;
+}
+bool merged_ok(const AttnBatch& b) {
+  if (!(bwd_merged_mode() & (b.hd == 32 ? 1 : 2)) || b.causal) return false;
+  for (int i = 0; i < b.n; ++i) {
+    const AttnProb& p = b.p[i];
+    if (p.Tq != p.Sk || !p.O || !p.dO || !p.dQ || !p.dK || !p.dV) return false;
+    if ((p.ldo & 7) || (p.lddq & 7)) return false;   // 16-byte row pieces
+    const int main_rows = p.Sk - tail_of(b, p.Sk);
+    if (main_rows < 1) return false;
+    if (b.hd == 8 ? main_rows > MCfg<8>::MAXQ : p.Sk > MCfg<32>::MAXQ) return false;
+  }
+  return true;
+}
+template <int HD>
+int launch_merged(AttnBatch& b, hipStream_t stream) {
+  typedef MCfg<HD> C;
+  int total = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.p[i].tail_o = b.p[i].tail_s = tail_of(b, b.p[i].Sk);
+    b.p[i].blocks_per_bh = 1;
+    b.p[i].block_begin = total;
+    total += b.p[i].B * (b.p[i].H / C::HG);
+  }
+  if (b.drop_p > 0.f) MMST_LAUNCH((attn_bwd_kernel<HD, true>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  else MMST_LAUNCH((attn_bwd_kernel<HD, false>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+}  // namespace
+
+void attn_set_bwd_merged(int mode) { g_bwd_merged = (mode >= 0 && mode <= 3) ? mode : -1; }   // other values: the default
+int attn_bwd_merged() { return bwd_merged_mode(); }
+
 int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {
-  int rc = launch_attn_bwd_q(b, stream);
+  int rc = check_bwd(b);
   if (rc) return rc;
+  if (merged_ok(b)) return b.hd == 32 ? launch_merged<32>(b, stream) : launch_merged<8>(b, stream);
+  // an armed completion event belongs to the LAST kernel of the backward
+  hipEvent_t ev = mmst_armed_stop_event;
+  mmst_armed_stop_event = nullptr;
+  rc = launch_attn_bwd_q(b, stream);
+  if (rc) return rc;
+  mmst_armed_stop_event = ev;
   return launch_attn_bwd_kv(b, stream);
 }
 
@@ -766,11 +1146,11 @@ int launch_attn_bwd_kv(AttnBatch& b, hipStream_t stream) {
   }
   dim3 grid(total), block(64 * NWAVES);
   if (b.hd == 32) {
-    if (b.causal) hipLaunchKernelGGL((attn_kv_kernel<32, true>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((attn_kv_kernel<32, false>), grid, block, 0, stream, b);
+    if (b.causal) MMST_LAUNCH((attn_kv_kernel<32, true>), grid, block, 0, stream, b);
+    else MMST_LAUNCH((attn_kv_kernel<32, false>), grid, block, 0, stream, b);
   } else {
-    if (b.causal) hipLaunchKernelGGL((attn_kv_kernel<8, true>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((attn_kv_kernel<8, false>), grid, block, 0, stream, b);
+    if (b.causal) MMST_LAUNCH((attn_kv_kernel<8, true>), grid, block, 0, stream, b);
+    else MMST_LAUNCH((attn_kv_kernel<8, false>), grid, block, 0, stream, b);
   }
   MMST_CHECK_LAUNCH();
   return MMST_OK;

@@ -226,7 +226,7 @@ int enc_bwd_ffn(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const 
 
 // second part of the critical path: out_proj, attention and in_proj backward.  Leaves dqkv in w.
 int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const mmst_enc_bwd* w, int nhead, float drop_p,
-                 uint32_t seed, hipStream_t st, bool da_done, hipEvent_t* done = nullptr) {
+                 uint32_t seed, hipStream_t st, bool da_done, hipEvent_t* done = nullptr, hipEvent_t* attn_done = nullptr) {
   const int hd = D / nhead;
   GemmBatch gb;
   gb.n = n;
@@ -253,6 +253,7 @@ int enc_bwd_attn(int n, const mmst_enc_params* p, const mmst_enc_acts* a, const 
     q.B = a[i].B; q.H = nhead; q.Tq = a[i].S; q.Sk = a[i].S;
     q.seed = seed + 8 * i + 0;
   }
+  if (attn_done) *attn_done = arm_completion_event();   // completion event of the last attention kernel: dqkv exists
   RUN(launch_attn_bwd(ab, st));
   // dx = dqkv Wqkv + dz1 ; fused with the previous layer's norm2 backward when there is one
   bool prev = w[0].prev_z2 != nullptr;
@@ -412,10 +413,20 @@ int mmst_encoder_layer_bwd_streams(int n, const mmst_enc_params* p, const mmst_e
     RUN(stream_fork(st, wst));
     RUN(enc_bwd_weights(n, p, g, a, w, drop_p, WG_EARLY, wst));
   }
-  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, da_done, &done));
+  // The projection gradients need dqkv only: they start behind the attention backward, beside the in_proj backward
+  // GEMM that ends the layer, instead of behind that GEMM (MMST_WGRAD_AFTER_ATTN=0 restores the later start); wstream
+  // is then ordered behind the GEMM as well, whose output the layer below reads first on that stream.
+  static const bool after_attn = [] { const char* e = getenv("MMST_WGRAD_AFTER_ATTN"); return e ? atoi(e) != 0 : true; }();
+  hipEvent_t attn_done = nullptr;
+  RUN(enc_bwd_attn(n, p, a, w, nhead, drop_p, seed, st, da_done, &done, after_attn ? &attn_done : nullptr));
+  const int which = ((interleave & 1) ? WG_LATE : (WG_EARLY | WG_LATE)) | (ffn_first ? WG_SKIP_FFN : 0);
+  if (after_attn) {
+    RUN(wait_for(wst, attn_done));
+    RUN(enc_bwd_weights(n, p, g, a, w, drop_p, which, wst));
+    return wait_for(wst, done);
+  }
   RUN(wait_for(wst, done));
-  return enc_bwd_weights(n, p, g, a, w, drop_p,
-                         ((interleave & 1) ? WG_LATE : (WG_EARLY | WG_LATE)) | (ffn_first ? WG_SKIP_FFN : 0), wst);
+  return enc_bwd_weights(n, p, g, a, w, drop_p, which, wst);
 }
 
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,

@@ -433,9 +433,20 @@ def run_attn(B, H, T, S, hd, causal, use_bias, p=0.0, seed=77, self_attn=True):
     close(gv.reshape(B, S, H, hd), vf.grad, rtol=3e-2, atol=3e-2)
 
 
+@pytest.fixture(params=[0, 3], ids=["bwd-two-pass", "bwd-one-pass"])
+def attn_bwd_mode(request):
+    """Both forms of the self-attention backward: two passes (dQ, then dK/dV) and the single-pass kernel (which serves
+    the shapes whose rows fit its LDS arrays; the others fall back to the two passes under either setting)."""
+    L.check(L.lib().mmst_attn_bwd_config(request.param), "mmst_attn_bwd_config")
+    assert L.lib().mmst_attn_bwd_mode() == request.param
+    yield request.param
+    L.check(L.lib().mmst_attn_bwd_config(-1), "mmst_attn_bwd_config")
+
+
 @pytest.mark.parametrize("B,H,S,hd", [(2, 16, 129, 8), (3, 16, 66, 8), (2, 4, 582, 32), (1, 4, 453, 32),
-                                       (2, 16, 193, 8), (1, 4, 902, 32)])
-def test_attn_self(B, H, S, hd):
+                                       (2, 16, 193, 8), (1, 4, 902, 32), (2, 16, 64, 8), (2, 4, 608, 32),
+                                       (3, 4, 33, 32), (2, 16, 97, 8)])
+def test_attn_self(B, H, S, hd, attn_bwd_mode):
     run_attn(B, H, S, S, hd, causal=False, use_bias=True)
 
 
@@ -449,6 +460,6 @@ def test_attn_cross(T, S):
     run_attn(2, 16, T, S, 8, causal=False, use_bias=True, self_attn=False)
 
 
-@pytest.mark.parametrize("hd,H,S", [(8, 16, 129), (32, 4, 300)])
-def test_attn_dropout(hd, H, S):
+@pytest.mark.parametrize("hd,H,S", [(8, 16, 129), (32, 4, 300), (32, 4, 582), (8, 16, 66)])
+def test_attn_dropout(hd, H, S, attn_bwd_mode):
     run_attn(2, H, S, S, hd, causal=False, use_bias=True, p=0.1)
