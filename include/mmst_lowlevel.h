@@ -104,6 +104,11 @@ typedef struct {
                                        * no dH and no hidden split reads these 256 B per row in place of the 4 KiB of H */
   float drop_p; uint32_t seed;
   int tile_begin, hsplit;             /* launcher */
+  const void* A; const void* Wp;      /* optional (forward): X = LN(pre.R + drop(A Wp^T + pre.bias)), the out_proj +
+                                       * dropout + residual + norm1 in front of the block (models_MMT_v15_4.py:497-509 via
+                                       * nn.TransformerEncoderLayer), computed by the same launch; pre = that GEMM's row
+                                       * epilogue (MMST_EPI_LN fields; pre.C must be X); Wp NULL = X is read */
+  mmst_gemm_prob pre;
 } mmst_ffn_prob;
 typedef struct { int n; mmst_ffn_prob p[6]; } mmst_ffn_batch;
 /* returns 0, a negative error code, or (backward only) 1 when the launch also wrote every problem's Cn */

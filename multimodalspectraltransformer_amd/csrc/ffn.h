@@ -29,6 +29,14 @@ struct FfnProb {
   uint32_t seed;
   int tile_begin;      // filled by the launcher
   int hsplit;          // filled by the launcher: workgroups per row tile (each walks 2048/hsplit hidden columns)
+  // Optional (forward): the linear layer and LayerNorm in FRONT of the block (out_proj + dropout + residual + norm1 of a
+  // transformer layer), X = LN(pre.R + drop(A Wp^T + pre.bias)).  pre is that GEMM's row epilogue (EPI_LN: C = X, Z,
+  // stats, R, bias, gamma, beta, drop_p, seed; C must be X).  The fused kernel without hidden split computes it as a
+  // prologue on its row tile (the rows go from the MFMA accumulators into the block without another launch); the other
+  // paths run it as a GEMM launch of its own first.
+  const bf16* A;       // [M][128] input of that linear layer (attention output)
+  const bf16* Wp;      // [128][128] its weight; null = no prologue, X is read
+  GemmProb pre;
 };
 
 struct FfnBatch {

@@ -413,10 +413,11 @@ template <bool DROP, int NW, bool SIGNS>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const FfnBatch batch) {
   typedef Shape<NW> S;
   constexpr int MT = S::MT, WD = S::WD;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4 + 6 * DM * 4];
   unsigned char* w1s = smem;             // 2 slots
   unsigned char* w2s = smem + 2 * SLOT;  // 2 slots
   float* b1s = reinterpret_cast<float*>(smem + 4 * SLOT);
+  float* vecs = b1s + FF;                // bias | gamma | beta of the final row epilogue, then of the prologue's
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0;
@@ -432,17 +433,55 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   const int pw0 = wave * 16 * MT;
   const int q = lane >> 4;
 
+  const bool has_pre = pr.Wp != nullptr && pr.hsplit == 1;
+  const bool wdma = NW == S::NWD || wave < S::NWD;   // this wave issues weight-image DMA
+  uint32_t offA[WD], offB[WD];
+#pragma unroll
+  for (int j = 0; j < WD; ++j) {
+    offA[j] = src_offset<IMG_W1_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
+    offB[j] = src_offset<IMG_W2_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
+  }
+  auto issue_w1 = [&](int c) {
+    unsigned char* dst = w1s + (c & 1) * SLOT + wave * WD * 1024;
+    if (wdma)
+#pragma unroll
+      for (int j = 0; j < WD; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
+  };
+  auto issue_w2 = [&](int c) {
+    unsigned char* dst = w2s + (c & 1) * SLOT + wave * WD * 1024;
+    if (wdma)
+#pragma unroll
+      for (int j = 0; j < WD; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
+  };
+  // Everything the first step needs is requested before anything is waited for: the first linear1 image and, with a
+  // prologue, the two 64-column halves of Wp as first-GEMM images in the (still unused) slots of the second weight.
+  if (wdma && has_pre) {
+#pragma unroll
+    for (int j = 0; j < WD; ++j) {
+      glds16(pr.Wp + offA[j], w2s + wave * WD * 1024 + j * 1024);
+      glds16(pr.Wp + offA[j] + chunk_stride<IMG_W1_FWD>(), w2s + SLOT + wave * WD * 1024 + j * 1024);
+    }
+  }
+  issue_w1(c0);
+  // token-side fragments: the block input, or (prologue) the input of the linear layer in front of it
   bf16x8 xf[MT][4];
   uint32_t hoff[MT], rseed[MT];
+  auto load_rows = [&](const bf16* src) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = p0 + pw0 + mt * 16 + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) v = *reinterpret_cast<const uint4*>(src + (size_t)m * DM + ks * 32 + 8 * q);
+        xf[mt][ks] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+  };
+  load_rows(has_pre ? pr.A : pr.X);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = p0 + pw0 + mt * 16 + (lane & 15);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < M) v = *reinterpret_cast<const uint4*>(pr.X + (size_t)m * DM + ks * 32 + 8 * q);
-      xf[mt][ks] = __builtin_bit_cast(bf16x8, v);
-    }
     hoff[mt] = ((uint32_t)m * FF + 8 * q) * 2;   // byte offset; rows >= M fall outside the descriptor and are dropped
     rseed[mt] = attn_row_seed(pr.seed, (uint32_t)m);
   }
@@ -450,6 +489,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   const float dscale = (DROP && pr.drop_p > 0.f) ? 1.0f / (1.0f - pr.drop_p) : 1.0f;
   for (int i = tid; i < FF / 4; i += NW * 64)
     *reinterpret_cast<f32x4*>(b1s + i * 4) = *reinterpret_cast<const f32x4*>(pr.b1 + i * 4) * dscale;
+  // the row epilogues read their vectors from LDS, not from memory at the end of a dependent chain
+  for (int i = tid; i < (has_pre ? 6 : 3) * DM; i += NW * 64) {
+    const GemmProb& e = i < 3 * DM ? pr.epi : pr.pre;
+    const int w = (i / DM) % 3, col = i % DM;
+    const float* src = w == 0 ? e.bias : (w == 1 ? e.gamma : e.beta);
+    vecs[i] = src ? src[col] : 0.f;
+  }
   // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
   const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
   // sign words of the hidden activation (see FfnProb::Hs): the 16 flags of a chunk are gathered with three operations
@@ -472,25 +518,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool wdma = NW == S::NWD || wave < S::NWD;   // this wave issues weight-image DMA
-  uint32_t offA[WD], offB[WD];
-#pragma unroll
-  for (int j = 0; j < WD; ++j) {
-    offA[j] = src_offset<IMG_W1_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
-    offB[j] = src_offset<IMG_W2_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
-  }
-  auto issue_w1 = [&](int c) {
-    unsigned char* dst = w1s + (c & 1) * SLOT + wave * WD * 1024;
-    if (wdma)
-#pragma unroll
-      for (int j = 0; j < WD; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
-  };
-  auto issue_w2 = [&](int c) {
-    unsigned char* dst = w2s + (c & 1) * SLOT + wave * WD * 1024;
-    if (wdma)
-#pragma unroll
-      for (int j = 0; j < WD; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
-  };
   auto qrow = [&](int nt) { return (nt >> 1) * 32 + 8 * ((lane & 15) >> 2) + 4 * (nt & 1) + (lane & 3); };
 
   const uint32_t thr = drop_threshold(pr.drop_p);
@@ -498,8 +525,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
 
   f32x4 a1[MT][4];
   bf16x8 hfp[MT][2];
-  auto gemm1 = [&](int c) __attribute__((always_inline)) {
-    const unsigned char* img = w1s + (c & 1) * SLOT;
+  auto gemm1_img = [&](const unsigned char* img) __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -516,6 +542,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
           a1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], xf[mt][ks], a1[mt][nt], 0, 0, 0);
     }
   };
+  auto gemm1 = [&](int c) __attribute__((always_inline)) { gemm1_img(w1s + (c & 1) * SLOT); };
   // Second GEMM of chunk c2 and hidden-chunk arithmetic of chunk c in ONE hand-ordered region: the 16 MT MFMAs go
   // out MT at a time, each group followed by one 2-column piece of the bias/ReLU/dropout/convert work (8 MT pieces
   // over 16 slots), so the vector ALU runs in the shadow of the matrix pipe.  has2 / hasc are compile-time (the region
@@ -616,12 +643,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   constexpr std::true_type yes{};
   constexpr std::false_type no{};
 
-  // prologue: step 0 has no second GEMM
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  issue_w1(c0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (has_pre) {
+    // X = LN(R + drop(A Wp^T + bias)) on this tile's rows: the 128 outputs of a row land in the accumulators in the row
+    // epilogue's layout, and the epilogue hands the rows back as the block's input fragments
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      gemm1_img(w2s + c * SLOT);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][4 * c + nt] = a1[mt][nt];
+    }
+    epi_ln(acc, pr.pre, p0, pw0, lane, xf, vecs + 3 * DM);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();   // every wave has read the Wp images: the second weight's slots may be filled
+  }
   issue_w1(c0 + 1);   // a workgroup walks at least four chunks
   issue_w2(c0);
   gemm1(c0);
@@ -650,7 +691,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   gemm2_hidden(yes, no, c1 - 1, -1);
 
   if (pr.hsplit > 1) store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
-  else epi_ln(acc, pr.epi, p0, pw0, lane);
+  else epi_ln(acc, pr.epi, p0, pw0, lane, nullptr, vecs);
 }
 
 int prepare(FfnBatch& b, bool bwd, int bpx) {
@@ -842,12 +883,40 @@ int signs_from_hidden(const FfnBatch& b, hipStream_t stream) {
 
 }  // namespace
 
+// The linear layer + LayerNorm in front of the block (FfnProb::Wp) as a grouped GEMM launch of its own, for the
+// paths whose kernels have no prologue; clears Wp.
+int pre_as_gemm(FfnBatch& b, hipStream_t stream) {
+  GemmBatch g;
+  g.n = b.n;
+  for (int i = 0; i < b.n; ++i) {
+    FfnProb& f = b.p[i];
+    GemmProb q = f.pre;
+    q.P = f.A; q.ldp = DM; q.Q = f.Wp; q.ldq = DM;
+    q.Pn = f.epi.Pn; q.Qn = DM; q.K = DM; q.ksplit = 1;
+    g.p[i] = q;
+    f.Wp = nullptr;
+  }
+  return launch_gemm(g, EPI_LN, false, false, stream);
+}
+
 int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
+  bool pre = b.p[0].Wp != nullptr;
+  for (int i = 0; i < b.n; ++i) {
+    FfnProb& f = b.p[i];
+    if ((f.Wp != nullptr) != pre) return MMST_ERR_ARG;   // all problems or none
+    if (pre && (!f.A || f.pre.C != (void*)f.X || f.pre.ldc != DM || f.pre.cS > 0 || !f.pre.gamma || !f.pre.beta))
+      return MMST_ERR_ARG;
+  }
+  static const bool pre_fused = [] { const char* e = getenv("MMST_FFN_PRE_FUSED"); return e ? atoi(e) != 0 : true; }();
   const int nw = pick_waves(b, false);
   int total = prepare(b, false, nw == 10 ? 160 : 128);
   if (total < 0) return MMST_ERR_ARG;
   const bool split = b.p[0].hsplit > 1;
+  if (pre && (split || total < fuse_min_tiles() || !pre_fused)) {
+    const int rc = pre_as_gemm(b, stream);
+    if (rc) return rc;
+  }
   if (!split && total < fuse_min_tiles()) {
     const int rc = ffn_fwd_unfused(b, stream);
     return rc ? rc : signs_from_hidden(b, stream);

@@ -166,9 +166,16 @@ __device__ __forceinline__ void add_slabs(f32x4 (&acc)[MT][8], const float* slab
 // ---- LayerNorm forward on a row-owning wave layout: acc[mt][nt] holds rows p0+pw0+mt*16+(lane&15), all 128
 // columns (MT = 2: 4 waves x 32 rows, MT = 1: 8 waves x 16 rows).
 // z = R + drop(acc + bias); C = LN(z) (row remap cS/cL/coff); Z = z; stats = (mean, rstd).
+// yf (optional): the output rows as MFMA token-side fragments (yf[mt][tp] = columns 32 tp + 8 q .. + 7 of the lane's row,
+// the values stored to C; zero for rows past the end), for a GEMM chained behind the epilogue.
+// vec (optional): bias | gamma | beta as 3 x 128 floats the caller has staged (in LDS) in place of pr.bias, pr.gamma, pr.beta.
 template <int MT>
-__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, int p0, int pw0, int lane) {
+__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, int p0, int pw0, int lane,
+                                       bf16x8 (*yf)[4] = nullptr, const float* vec = nullptr) {
   const int q = lane >> 4;
+  const float* bias_v = vec ? vec : pr.bias;
+  const float* gamma_v = vec ? vec + 128 : pr.gamma;
+  const float* beta_v = vec ? vec + 256 : pr.beta;
   auto crow = [&](int m) -> size_t { return pr.cS > 0 ? (size_t)(m / pr.cS) * pr.cL + pr.coff + (m % pr.cS) : (size_t)m; };
   auto rrow = [&](int m) -> size_t { return pr.rS > 0 ? (size_t)(m / pr.rS) * pr.rL + pr.roff + (m % pr.rS) : (size_t)m; };
   const uint32_t thr = drop_threshold(pr.drop_p);
@@ -184,9 +191,9 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
       const int n = tp * 32 + 8 * q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { z[tp][e] = acc[mt][2 * tp][e]; z[tp][4 + e] = acc[mt][2 * tp + 1][e]; }
-      if (pr.bias) {
+      if (bias_v) {
         float b[8];
-        load8f(b, pr.bias + n);
+        load8f(b, bias_v + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[tp][e] += b[e];
       }
@@ -217,13 +224,22 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
         const int n = tp * 32 + 8 * q;
         if (pr.Z) store8(pr.Z + (size_t)m * 128 + n, z[tp]);
         float y[8], gam[8], bet[8];   // scale and shift are read where they are used (cache hits): 64 fewer live registers
-        load8f(gam, pr.gamma + n);
-        load8f(bet, pr.beta + n);
+        load8f(gam, gamma_v + n);
+        load8f(bet, beta_v + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = (z[tp][e] - mean) * rstd * gam[e] + bet[e];
-        store8((bf16*)pr.C + crow(m) * pr.ldc + n, y);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)y[e];
+        *reinterpret_cast<bf16x8*>((bf16*)pr.C + crow(m) * pr.ldc + n) = o;
+        if (yf) yf[mt][tp] = o;
       }
       if (q == 0 && pr.stats) { pr.stats[2 * (size_t)m] = mean; pr.stats[2 * (size_t)m + 1] = rstd; }
+    } else if (yf) {
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yf[mt][tp][e] = (bf16)0.f;
     }
   }
 }

@@ -165,16 +165,8 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
     q.seed = seed + 8 * i + 0;
   }
   RUN(launch_attn_fwd(ab, st));
-  // 3. out_proj + dropout + residual + norm1
-  for (int i = 0; i < n; ++i) {
-    GemmProb g = fwd_linear(a[i].attn, a[i].B * a[i].S, D, p[i].w_o, D, p[i].b_o, a[i].x1);
-    g.R = (const bf16*)a[i].x; g.ldr = D;
-    g.gamma = p[i].g1; g.beta = p[i].be1; g.Z = (bf16*)a[i].z1; g.stats = a[i].st1;
-    g.drop_p = drop_p; g.seed = seed + 8 * i + 1;
-    gb.p[i] = g;
-  }
-  RUN(launch_gemm(gb, EPI_LN, false, false, st));
-  // 4. feed-forward block + norm2, one kernel
+  // 3. out_proj + dropout + residual + norm1 and 4. feed-forward block + norm2: one launch (the fused feed-forward
+  // kernel runs step 3 as a prologue on its row tile; with few rows step 3 is a grouped GEMM launch of its own)
   FfnBatch fb;
   fb.n = n;
   for (int i = 0; i < n; ++i) {
@@ -182,6 +174,12 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
                              a[i].z2, a[i].st2, a[i].y, drop_p, seed + 8 * i + 2, seed + 8 * i + 3);
     if (a[i].y_L > 0) { f.epi.cS = a[i].S; f.epi.cL = a[i].y_L; f.epi.coff = a[i].y_off; }
     f.Hs = ffn_bwd_signs() ? (uint32_t*)a[i].hsign : nullptr;
+    GemmProb g = fwd_linear(a[i].attn, a[i].B * a[i].S, D, p[i].w_o, D, p[i].b_o, a[i].x1);
+    g.R = (const bf16*)a[i].x; g.ldr = D;
+    g.gamma = p[i].g1; g.beta = p[i].be1; g.Z = (bf16*)a[i].z1; g.stats = a[i].st1;
+    g.drop_p = drop_p; g.seed = seed + 8 * i + 1;
+    f.pre = g;
+    f.A = (const bf16*)a[i].attn; f.Wp = (const bf16*)p[i].w_o;
     fb.p[i] = f;
   }
   RUN(launch_ffn_fwd(fb, st));

@@ -65,7 +65,7 @@ def attn_bwd_launch(batch):
     L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
 
 
-_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws", "Wn", "Cn", "Hs")
+_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws", "Wn", "Cn", "Hs", "A", "Wp")
 
 
 def ffn_batch(groups):
@@ -77,9 +77,10 @@ def ffn_batch(groups):
     for i, g in enumerate(groups):
         p = b.p[i]
         for k, v in g.items():
-            if k == "epi":
+            if k in ("epi", "pre"):
+                sub = getattr(p, k)
                 for ek, ev in v.items():
-                    setattr(p.epi, ek, (L.ptr(ev) if isinstance(ev, torch.Tensor) else ev) if ek in _PTR_FIELDS else ev)
+                    setattr(sub, ek, (L.ptr(ev) if isinstance(ev, torch.Tensor) else ev) if ek in _PTR_FIELDS else ev)
             elif k in _FPTR:
                 setattr(p, k, L.ptr(v) if isinstance(v, torch.Tensor) else v)
             else:
