@@ -86,6 +86,12 @@ typedef struct {  /* backward state of ONE layer for ONE sequence group */
  * nn.TransformerEncoderLayer.forward as called from :846,:866,:886,:906,:927,:944. */
 int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
                            uint32_t seed, void* stream);
+/* nl layers of ONE encoder stack in sequence (layer l + 1 reads what layer l wrote; p[l] / a[l] as for
+ * mmst_encoder_layer_fwd, seeds[l] = that layer's dropout seed): the loop over self.layers of nn.TransformerEncoder
+ * (models_MMT_v15_4.py:846,:866,:886,:906,:927,:944).  Same results as nl calls of mmst_encoder_layer_fwd; a layer's QKV
+ * projection is chained behind the feed-forward kernel of the layer in front where that kernel can do it. */
+int mmst_encoder_stack_fwd(int n, int nl, const mmst_enc_params* const* p, const mmst_enc_acts* const* a, int nhead,
+                           float drop_p, const uint32_t* seeds, void* stream);
 /* Backward of the above (what autograd does for the reference) = _data followed by _weights. */
 int mmst_encoder_layer_bwd(int n, const mmst_enc_params* p, const mmst_enc_grads* g, const mmst_enc_acts* a,
                            const mmst_enc_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);

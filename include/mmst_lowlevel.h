@@ -109,9 +109,14 @@ typedef struct {
                                        * nn.TransformerEncoderLayer), computed by the same launch; pre = that GEMM's row
                                        * epilogue (MMST_EPI_LN fields; pre.C must be X); Wp NULL = X is read */
   mmst_gemm_prob pre;
+  const void* Wq; const float* bq;    /* optional (forward): Cq[M][nq] = Y Wq^T + bq on the rows the block has produced (the
+                                       * in_proj of the next layer); computed only by the fused kernel without hidden split
+                                       * and row remap: mmst_ffn then returns 2 */
+  void* Cq; int nq;                   /* nq: a multiple of 64, at most 384 */
 } mmst_ffn_prob;
 typedef struct { int n; mmst_ffn_prob p[6]; } mmst_ffn_batch;
-/* returns 0, a negative error code, or (backward only) 1 when the launch also wrote every problem's Cn */
+/* returns 0, a negative error code, (backward only) 1 when the launch also wrote every problem's Cn, or (forward only)
+ * 2 when it also wrote every problem's Cq */
 int mmst_ffn(const mmst_ffn_batch* batch, int backward, void* stream);
 
 /* weight gradients of the block with the hidden gradient recomputed in the kernel (accumulating) */

@@ -58,7 +58,8 @@ class FfnProb(C.Structure):
     _fields_ = [("epi", GemmProb), ("X", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("b1", C.c_void_p),
                 ("H", C.c_void_p), ("dH", C.c_void_p), ("ws", C.c_void_p), ("Wn", C.c_void_p), ("Cn", C.c_void_p),
                 ("Hs", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
-                ("tile_begin", C.c_int), ("hsplit", C.c_int), ("A", C.c_void_p), ("Wp", C.c_void_p), ("pre", GemmProb)]
+                ("tile_begin", C.c_int), ("hsplit", C.c_int), ("A", C.c_void_p), ("Wp", C.c_void_p), ("pre", GemmProb),
+                ("Wq", C.c_void_p), ("bq", C.c_void_p), ("Cq", C.c_void_p), ("nq", C.c_int)]
 
 
 class FfnBatch(C.Structure):

@@ -20,7 +20,7 @@ static_assert(sizeof(mmst_attn_prob) == sizeof(AttnProb) && sizeof(mmst_attn_bat
 static_assert(sizeof(mmst_ffn_prob) == sizeof(FfnProb) && sizeof(mmst_ffn_batch) == sizeof(FfnBatch) &&
               offsetof(mmst_ffn_prob, X) == offsetof(FfnProb, X) && offsetof(mmst_ffn_prob, Cn) == offsetof(FfnProb, Cn) && offsetof(mmst_ffn_prob, Hs) == offsetof(FfnProb, Hs) &&
               offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit) && offsetof(mmst_ffn_prob, Wp) == offsetof(FfnProb, Wp) &&
-              offsetof(mmst_ffn_prob, pre) == offsetof(FfnProb, pre), "ffn ABI");
+              offsetof(mmst_ffn_prob, pre) == offsetof(FfnProb, pre) && offsetof(mmst_ffn_prob, nq) == offsetof(FfnProb, nq), "ffn ABI");
 static_assert(sizeof(mmst_ffn_wgrad_prob) == sizeof(FfnWgradProb) && sizeof(mmst_ffn_wgrad_batch) == sizeof(FfnWgradBatch) &&
               offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M) && offsetof(mmst_ffn_wgrad_prob, rs) == offsetof(FfnWgradProb, rs), "ffn weight-gradient ABI");
 static_assert(MMST_GEMM_MAX_GROUPS == GEMM_MAX_GROUPS && MMST_EPI_ATOMIC == EPI_ATOMIC && MMST_GF_OUT_F32 == GF_OUT_F32, "gemm ABI");
@@ -49,7 +49,11 @@ int mmst_attn_bwd(const mmst_attn_batch* batch, void* stream) {
 int mmst_ffn(const mmst_ffn_batch* batch, int backward, void* stream) {
   if (!batch) return MMST_ERR_ARG;
   FfnBatch b = *reinterpret_cast<const FfnBatch*>(batch);
-  if (!backward) return launch_ffn_fwd(b, (hipStream_t)stream);
+  if (!backward) {
+    bool post_done = false;
+    const int rc = launch_ffn_fwd(b, (hipStream_t)stream, &post_done);
+    return rc != MMST_OK ? rc : (post_done ? 2 : 0);
+  }
   bool next_done = false;
   const int rc = launch_ffn_bwd(b, (hipStream_t)stream, &next_done);
   return rc != MMST_OK ? rc : (next_done ? 1 : 0);

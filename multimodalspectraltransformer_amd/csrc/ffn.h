@@ -37,6 +37,13 @@ struct FfnProb {
   const bf16* A;       // [M][128] input of that linear layer (attention output)
   const bf16* Wp;      // [128][128] its weight; null = no prologue, X is read
   GemmProb pre;
+  // Optional (forward): a linear layer BEHIND the block on the rows it has just produced, Cq[M][nq] = Y Wq^T + bq (the
+  // in_proj of the next transformer layer, nq = 384).  Only the fused kernel without hidden split and without a row
+  // remap of its output computes it (launch_ffn_fwd reports whether it did); otherwise the caller launches that GEMM.
+  const bf16* Wq;      // [nq][128]; null = nothing chained
+  const float* bq;     // [nq] or null
+  bf16* Cq;
+  int nq;              // a multiple of 64, at most 384
 };
 
 struct FfnBatch {
@@ -63,7 +70,8 @@ struct FfnWgradBatch {
 };
 int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream);
 
-int launch_ffn_fwd(FfnBatch& b, hipStream_t stream);
+// post_done (optional): set to whether the launch also produced Cq of every problem
+int launch_ffn_fwd(FfnBatch& b, hipStream_t stream, bool* post_done = nullptr);
 // next_done (optional): set to whether the launch also produced Cn = E Wn (only the fused kernel without hidden split does)
 int launch_ffn_bwd(FfnBatch& b, hipStream_t stream, bool* next_done = nullptr);
 // Launches with fewer 128-row tiles than this run as two grouped GEMM launches instead of the fused kernel

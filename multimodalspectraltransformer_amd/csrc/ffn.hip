@@ -413,11 +413,12 @@ template <bool DROP, int NW, bool SIGNS>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const FfnBatch batch) {
   typedef Shape<NW> S;
   constexpr int MT = S::MT, WD = S::WD;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4 + 6 * DM * 4];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4 + 9 * DM * 4];
   unsigned char* w1s = smem;             // 2 slots
   unsigned char* w2s = smem + 2 * SLOT;  // 2 slots
   float* b1s = reinterpret_cast<float*>(smem + 4 * SLOT);
-  float* vecs = b1s + FF;                // bias | gamma | beta of the final row epilogue, then of the prologue's
+  float* vecs = b1s + FF;                // bias | gamma | beta of the final row epilogue, then of the prologue's,
+                                         // then the bias of the chained linear layer (up to 384 columns)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0;
@@ -496,6 +497,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
     const float* src = w == 0 ? e.bias : (w == 1 ? e.gamma : e.beta);
     vecs[i] = src ? src[col] : 0.f;
   }
+  const bool has_post = pr.Wq != nullptr && pr.hsplit == 1;
+  if (has_post)
+    for (int i = tid; i < pr.nq; i += NW * 64) vecs[6 * DM + i] = pr.bq ? pr.bq[i] : 0.f;
   // hidden activation goes out through a buffer descriptor: the range check replaces a per-row branch
   const auto hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pr.H, 0, (int)((uint32_t)M * FF * 2), 0x00020000);
   // sign words of the hidden activation (see FfnProb::Hs): the 16 flags of a chunk are gathered with three operations
@@ -688,10 +692,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   step(yes, c1 - 1);
   wait_images();
   __builtin_amdgcn_s_barrier();
+  // Chained linear layer: its weight arrives as first-GEMM images, 64 output columns each; the first two are requested
+  // here (every wave is past its last first GEMM) and land during the last second GEMM and the row epilogue.
+  const int nqc = has_post ? pr.nq / HC : 0;
+  auto issue_wq = [&](int c) {
+    unsigned char* dst = w1s + (c & 1) * SLOT + wave * WD * 1024;
+    if (wdma)
+#pragma unroll
+      for (int j = 0; j < WD; ++j) glds16(pr.Wq + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
+  };
+  if (nqc > 0) issue_wq(0);
+  if (nqc > 1) issue_wq(1);
   gemm2_hidden(yes, no, c1 - 1, -1);
 
-  if (pr.hsplit > 1) store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
-  else epi_ln(acc, pr.epi, p0, pw0, lane, nullptr, vecs);
+  if (pr.hsplit > 1) {
+    store_slab(acc, pr.ws + (size_t)hs * M * DM, M, p0, pw0, lane);
+    return;
+  }
+  epi_ln(acc, pr.epi, p0, pw0, lane, has_post ? xf : nullptr, vecs);
+  for (int c = 0; c < nqc; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own portions of image c (and the stores behind it)
+    __builtin_amdgcn_s_barrier();                        // everyone's; and image c - 1 has been read by every wave
+    if (c >= 1 && c + 1 < nqc) issue_wq(c + 1);
+    gemm1_img(w1s + (c & 1) * SLOT);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = p0 + pw0 + mt * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        float v[8], bb[8];
+        load8f(bb, vecs + 6 * DM + c * HC + tp * 32 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a1[mt][2 * tp][e] + bb[e]; v[4 + e] = a1[mt][2 * tp + 1][e] + bb[4 + e]; }
+        store8(pr.Cq + (size_t)m * pr.nq + c * HC + tp * 32 + 8 * q, v);
+      }
+    }
+  }
 }
 
 int prepare(FfnBatch& b, bool bwd, int bpx) {
@@ -899,9 +936,17 @@ int pre_as_gemm(FfnBatch& b, hipStream_t stream) {
   return launch_gemm(g, EPI_LN, false, false, stream);
 }
 
-int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
+int launch_ffn_fwd(FfnBatch& b, hipStream_t stream, bool* post_done) {
+  if (post_done) *post_done = false;
   if (b.n < 1 || b.n > FFN_MAX_GROUPS) return MMST_ERR_ARG;
   bool pre = b.p[0].Wp != nullptr;
+  // the chained linear layer is all problems or none, and needs the rows where the next launch reads them
+  static const bool post_fused = [] { const char* e = getenv("MMST_FFN_POST_FUSED"); return e ? atoi(e) != 0 : true; }();
+  bool post = post_fused;
+  for (int i = 0; i < b.n; ++i) {
+    const FfnProb& f = b.p[i];
+    post = post && f.Wq != nullptr && f.Cq != nullptr && f.nq >= HC && f.nq <= 3 * DM && f.nq % HC == 0 && f.epi.cS == 0;
+  }
   for (int i = 0; i < b.n; ++i) {
     FfnProb& f = b.p[i];
     if ((f.Wp != nullptr) != pre) return MMST_ERR_ARG;   // all problems or none
@@ -917,6 +962,10 @@ int launch_ffn_fwd(FfnBatch& b, hipStream_t stream) {
     const int rc = pre_as_gemm(b, stream);
     if (rc) return rc;
   }
+  post = post && !split && total >= fuse_min_tiles();
+  if (!post)
+    for (int i = 0; i < b.n; ++i) b.p[i].Wq = nullptr;
+  else if (post_done) *post_done = true;
   if (!split && total < fuse_min_tiles()) {
     const int rc = ffn_fwd_unfused(b, stream);
     return rc ? rc : signs_from_hidden(b, stream);

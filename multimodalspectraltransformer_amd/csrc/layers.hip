@@ -137,19 +137,25 @@ inline FfnProb ffn_bwd_prob(const void* dzd, const void* dz, int M, const void* 
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
-                           uint32_t seed, void* stream_) {
+// One encoder layer.  qkv_ready: the layer's QKV projection exists already (the launch of the layer in front chained
+// it).  pn / an (optional): parameters and buffers of the NEXT layer of the same stack, whose input is this layer's
+// output: its QKV projection is then chained behind this layer's feed-forward kernel when that kernel can do it
+// (*next_qkv_done says so).
+int enc_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p, uint32_t seed,
+                  hipStream_t st, bool qkv_ready, const mmst_enc_params* pn, const mmst_enc_acts* an, bool* next_qkv_done) {
+  if (next_qkv_done) *next_qkv_done = false;
   if (n < 1 || n > MMST_MAX_GROUPS || !p || !a || (nhead != 16 && nhead != 4)) return MMST_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream_;
   const int hd = D / nhead;
   GemmBatch gb;
   AttnBatch ab;
   // 1. fused QKV projection
   gb.n = n;
-  for (int i = 0; i < n; ++i) gb.p[i] = fwd_linear(a[i].x, a[i].B * a[i].S, D, p[i].w_qkv, 3 * D, p[i].b_qkv, a[i].qkv);
-  RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  if (!qkv_ready) {
+    for (int i = 0; i < n; ++i) gb.p[i] = fwd_linear(a[i].x, a[i].B * a[i].S, D, p[i].w_qkv, 3 * D, p[i].b_qkv, a[i].qkv);
+    RUN(launch_gemm(gb, EPI_BIAS, false, false, st));
+  }
   // 2. attention
   memset(&ab, 0, sizeof(ab));
   ab.n = n; ab.hd = hd; ab.causal = 0; ab.drop_p = drop_p;
@@ -182,7 +188,39 @@ int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts*
     f.A = (const bf16*)a[i].attn; f.Wp = (const bf16*)p[i].w_o;
     fb.p[i] = f;
   }
-  RUN(launch_ffn_fwd(fb, st));
+  bool chain = pn && an && next_qkv_done;
+  for (int i = 0; chain && i < n; ++i)
+    chain = an[i].x == a[i].y && a[i].y_L <= 0 && an[i].B == a[i].B && an[i].S == a[i].S && an[i].qkv && pn[i].w_qkv;
+  if (chain)
+    for (int i = 0; i < n; ++i) {
+      fb.p[i].Wq = (const bf16*)pn[i].w_qkv; fb.p[i].bq = pn[i].b_qkv; fb.p[i].Cq = (bf16*)an[i].qkv; fb.p[i].nq = 3 * D;
+    }
+  return launch_ffn_fwd(fb, st, next_qkv_done);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmst_encoder_layer_fwd(int n, const mmst_enc_params* p, const mmst_enc_acts* a, int nhead, float drop_p,
+                           uint32_t seed, void* stream_) {
+  return enc_layer_fwd(n, p, a, nhead, drop_p, seed, (hipStream_t)stream_, false, nullptr, nullptr, nullptr);
+}
+
+// nl layers of one encoder stack in sequence (layer l + 1 reads what layer l wrote): the same launches as nl calls of
+// mmst_encoder_layer_fwd, except that a layer's QKV projection is chained behind the feed-forward kernel of the layer in
+// front wherever that kernel can do it (large row counts, no row remap of the output).
+int mmst_encoder_stack_fwd(int n, int nl, const mmst_enc_params* const* p, const mmst_enc_acts* const* a, int nhead,
+                           float drop_p, const uint32_t* seeds, void* stream_) {
+  if (nl < 1 || nl > MMST_MAX_LAYERS || !p || !a || !seeds) return MMST_ERR_ARG;
+  bool ready = false;
+  for (int l = 0; l < nl; ++l) {
+    bool next_done = false;
+    const bool more = l + 1 < nl;
+    RUN(enc_layer_fwd(n, p[l], a[l], nhead, drop_p, seeds[l], (hipStream_t)stream_, ready, more ? p[l + 1] : nullptr,
+                      more ? a[l + 1] : nullptr, more ? &next_done : nullptr));
+    ready = next_done;
+  }
   return MMST_OK;
 }
 

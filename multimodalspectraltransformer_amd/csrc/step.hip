@@ -76,12 +76,11 @@ int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed
     q.Pn = B; q.Qn = D; q.K = IR_BINS; q.flags = GF_RELU;
     RUN(one_gemm(q, EPI_BIAS, false, false, st));
   }
-  for (int l = 0; l < nl; ++l)
-    RUN(mmst_encoder_layer_fwd(n, pl->modal_p[l], pl->modal_a[l], 16, ar->drop_layers,
-                               layer_seed(ar->step_seed, UID_MODAL + l), st));
-  for (int l = 0; l < nl; ++l)
-    RUN(mmst_encoder_layer_fwd(1, pl->cross_p[l], pl->cross_a[l], pl->cross_heads, ar->drop_layers,
-                               layer_seed(ar->step_seed, UID_CROSS + l), st));
+  uint32_t seeds[MMST_MAX_LAYERS];
+  for (int l = 0; l < nl; ++l) seeds[l] = layer_seed(ar->step_seed, UID_MODAL + l);
+  RUN(mmst_encoder_stack_fwd(n, nl, pl->modal_p, pl->modal_a, 16, ar->drop_layers, seeds, st));
+  for (int l = 0; l < nl; ++l) seeds[l] = layer_seed(ar->step_seed, UID_CROSS + l);
+  RUN(mmst_encoder_stack_fwd(1, nl, pl->cross_p, pl->cross_a, pl->cross_heads, ar->drop_layers, seeds, st));
   RUN(mmst_seq_mean(pl->memory, pl->mean, B, L, st));
   {
     GemmProb q = zero_prob();

@@ -65,7 +65,7 @@ def attn_bwd_launch(batch):
     L.check(L.lib().mmst_attn_bwd(C.byref(batch), L.stream_ptr()), "mmst_attn_bwd")
 
 
-_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws", "Wn", "Cn", "Hs", "A", "Wp")
+_FPTR = ("X", "W1", "W2", "b1", "H", "dH", "ws", "Wn", "Cn", "Hs", "A", "Wp", "Wq", "bq", "Cq")
 
 
 def ffn_batch(groups):
