@@ -139,12 +139,13 @@ int mmst_ffn_config(int fuse_min_tiles);
  * stores the hidden gradient and a split-K GEMM reads it; negative: back to the default */
 int mmst_ffn_wgrad_config(int recompute);
 int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1, 2 or 3 */
-/* mmst_attn_bwd on self-attention without a causal mask (the encoder layers; torch call site
- * nn.MultiheadAttention backward): bit 0 / bit 1 set = head_dim 32 / head_dim 8 launches whose rows fit (608 / 128
- * tiled rows) run ONE kernel that evaluates the probabilities once for dQ, dK and dV; clear = two passes (dQ, then
- * dK/dV).  Default 1; negative: back to the default.  Both forms give the same results to bf16 rounding. */
+/* mmst_attn_bwd on self-attention (the encoder layers and the decoder's causal self-attention; torch call site
+ * nn.MultiheadAttention backward): launches whose rows fit (head_dim 32: 608 rows; head_dim 8: 128 tiled rows) can
+ * run ONE kernel that evaluates the probabilities once for dQ, dK and dV instead of two passes (dQ, then dK/dV).
+ * Bits of `mode`: 0 = head_dim 32, 1 = head_dim 8 without a mask, 2 = head_dim 8 with the causal mask.  Default 1;
+ * negative: back to the default.  Both forms give the same results to bf16 rounding. */
 int mmst_attn_bwd_config(int mode);
-int mmst_attn_bwd_mode(void);    /* the setting in force: 0..3 */
+int mmst_attn_bwd_mode(void);    /* the setting in force: 0..7 */
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */

@@ -40,6 +40,6 @@ int launch_attn_bwd(AttnBatch& b, hipStream_t stream);      // = _q followed by 
 int launch_attn_bwd_q(AttnBatch& b, hipStream_t stream);    // dQ, delta
 int launch_attn_bwd_kv(AttnBatch& b, hipStream_t stream);   // dK, dV (reads delta)
 // Single-pass backward (dQ, dK, dV from one evaluation of the probabilities) for self-attention without a causal mask:
-// bit 0 = head_dim 32, bit 1 = head_dim 8; other values restore the default (attn.hip)
+// bit 0 = head_dim 32, bit 1 = head_dim 8, bit 2 = head_dim 8 with a causal mask; other values restore the default (attn.hip)
 void attn_set_bwd_merged(int mode);
 int attn_bwd_merged();

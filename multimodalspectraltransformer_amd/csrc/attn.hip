@@ -727,7 +727,7 @@ template <int HD> __device__ __forceinline__ float row_delta(const AttnProb& pr,
   return s;
 }
 
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool CAUSAL = false>
 __global__ __launch_bounds__(MCfg<HD>::NW * 64, 1) void attn_bwd_kernel(const AttnBatch batch) {
   typedef MCfg<HD> C;
   constexpr int NW = C::NW, HG = C::HG, WPH = C::WPH, KS = C::KS, GCM = C::GCM, NTHR = NW * 64;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(MCfg<HD>::NW * 64, 1) void attn_bwd_kernel(const At
   const int r = lane & 31, h = lane >> 5;
   const int hl = wave % HG, part = wave / HG, hoff = hl * HD, gcol = hg * GCM;
   const int hh = hg * HG + hl, H = pr.H, S = pr.Sk;
-  const int tail = HD == 8 ? pr.tail_o : 0;
+  const int tail = (HD == 8 && !CAUSAL) ? pr.tail_o : 0;
   const int S_main = S - tail;
   const float* lse_s = lse_all + hl * KC;
   const float* del_s = del_all + hl * KC;
@@ -890,7 +890,8 @@ __global__ __launch_bounds__(MCfg<HD>::NW * 64, 1) void attn_bwd_kernel(const At
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int i = 4 * g4 + j;
-              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, bias2 - ll[j]));
+              float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, bias2 - ll[j]));
+              if (CAUSAL && key > c0 + lq0 + 8 * g4 + 4 * h + j) p = 0.f;   // the key lies behind the query
               float d = dpacc[i];
               float pk = p;
               if (dropping) {
@@ -1069,10 +1070,12 @@ int launch_attn_bwd_q(AttnBatch& b, hipStream_t stream) {
 }
 
 namespace {
-// The single-pass kernel serves self-attention without a causal mask whose tiled rows fit its dQ array
+// The single-pass kernel serves self-attention (causal only with head_dim 8) whose tiled rows fit its dQ array
 // (head_dim 8: at most 128 rows beside the tail rows; head_dim 32: at most 608).  Setting (attn_set_bwd_merged, or
-// the environment variable MMST_ATTN_BWD_MERGED): bit 0 = use it for head_dim 32, bit 1 = for head_dim 8; 0 = the
-// two-pass form everywhere.  Default 1.  Measured at 64 molecules, alone on the GPU: head_dim 32 (582 rows) 128 us
+// the environment variable MMST_ATTN_BWD_MERGED): bit 0 = use it for head_dim 32, bit 1 = for head_dim 8, bit 2 = for
+// head_dim 8 with a causal mask (the decoder's self-attention; the causal form walks every tile and masks inside:
+// measured 0.02 ms slower per training step than the two 14 us launches it replaces); 0 = the two-pass form
+// everywhere.  Default 1.  Measured at 64 molecules, alone on the GPU: head_dim 32 (582 rows) 128 us
 // against 173 us for the two passes, head_dim 8 (3 x 129 + 66 rows) 111 us against 109 us (its workgroups need 150 KiB
 // of LDS for eight waves).  Inside a training step the head_dim 32 kernel is time-neutral: its 158 KiB of LDS keep
 // it off a CU while a feed-forward weight-gradient workgroup of the other stream (82 KiB) is resident, so the two
@@ -1082,12 +1085,13 @@ int bwd_merged_mode() {
   if (g_bwd_merged < 0) {
     const char* e = getenv("MMST_ATTN_BWD_MERGED");
     const int v = e ? atoi(e) : 1;
-    g_bwd_merged = (v >= 0 && v <= 3) ? v : 1;
+    g_bwd_merged = (v >= 0 && v <= 7) ? v : 1;
   }
   return g_bwd_merged;
 }
 bool merged_ok(const AttnBatch& b) {
-  if (!(bwd_merged_mode() & (b.hd == 32 ? 1 : 2)) || b.causal) return false;
+  if (b.causal && b.hd != 8) return false;
+  if (!(bwd_merged_mode() & (b.hd == 32 ? 1 : (b.causal ? 4 : 2)))) return false;
   for (int i = 0; i < b.n; ++i) {
     const AttnProb& p = b.p[i];
     if (p.Tq != p.Sk || !p.O || !p.dO || !p.dQ || !p.dK || !p.dV) return false;
@@ -1108,14 +1112,20 @@ int launch_merged(AttnBatch& b, hipStream_t stream) {
     b.p[i].block_begin = total;
     total += b.p[i].B * (b.p[i].H / C::HG);
   }
-  if (b.drop_p > 0.f) MMST_LAUNCH((attn_bwd_kernel<HD, true>), dim3(total), dim3(C::NW * 64), 0, stream, b);
-  else MMST_LAUNCH((attn_bwd_kernel<HD, false>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  if (HD == 8 && b.causal) {
+    if (b.drop_p > 0.f) MMST_LAUNCH((attn_bwd_kernel<8, true, true>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+    else MMST_LAUNCH((attn_bwd_kernel<8, false, true>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  } else if (b.drop_p > 0.f) {
+    MMST_LAUNCH((attn_bwd_kernel<HD, true>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  } else {
+    MMST_LAUNCH((attn_bwd_kernel<HD, false>), dim3(total), dim3(C::NW * 64), 0, stream, b);
+  }
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }
 }  // namespace
 
-void attn_set_bwd_merged(int mode) { g_bwd_merged = (mode >= 0 && mode <= 3) ? mode : -1; }   // other values: the default
+void attn_set_bwd_merged(int mode) { g_bwd_merged = (mode >= 0 && mode <= 7) ? mode : -1; }   // other values: the default
 int attn_bwd_merged() { return bwd_merged_mode(); }
 
 int launch_attn_bwd(AttnBatch& b, hipStream_t stream) {

@@ -433,7 +433,7 @@ def run_attn(B, H, T, S, hd, causal, use_bias, p=0.0, seed=77, self_attn=True):
     close(gv.reshape(B, S, H, hd), vf.grad, rtol=3e-2, atol=3e-2)
 
 
-@pytest.fixture(params=[0, 3], ids=["bwd-two-pass", "bwd-one-pass"])
+@pytest.fixture(params=[0, 7], ids=["bwd-two-pass", "bwd-one-pass"])
 def attn_bwd_mode(request):
     """Both forms of the self-attention backward: two passes (dQ, then dK/dV) and the single-pass kernel (which serves
     the shapes whose rows fit its LDS arrays; the others fall back to the two passes under either setting)."""
@@ -450,9 +450,13 @@ def test_attn_self(B, H, S, hd, attn_bwd_mode):
     run_attn(B, H, S, S, hd, causal=False, use_bias=True)
 
 
-@pytest.mark.parametrize("T", [1, 5, 63, 128])
-def test_attn_causal(T):
+@pytest.mark.parametrize("T", [1, 5, 63, 128, 33, 64])
+def test_attn_causal(T, attn_bwd_mode):
     run_attn(2, 16, T, T, 8, causal=True, use_bias=False)
+
+
+def test_attn_causal_dropout(attn_bwd_mode):
+    run_attn(2, 16, 63, 63, 8, causal=True, use_bias=False, p=0.1)
 
 
 @pytest.mark.parametrize("T,S", [(63, 582), (1, 453), (128, 902), (65, 130), (129, 64), (64, 98), (1, 66), (2, 130), (1, 128), (1, 7), (2, 9)])
