@@ -73,7 +73,7 @@ int mmst_ffn_config(int fuse_min_tiles) {
 }
 // 1 / 2: feed-forward weight gradients of fused launches recompute the hidden gradient (4- / 8-wave kernel shape);
 // 3: as 1 with the sign words of the hidden activation handed from the forward to the backward launch of a layer;
-// 0: they read a stored one; negative: the default (1, or what MMST_FFN_WGRAD_RECOMPUTE says)
+// 0: they read a stored one; negative: the default (0, or what MMST_FFN_WGRAD_RECOMPUTE says)
 int mmst_ffn_wgrad_config(int recompute) {
   ffn_set_wgrad_recompute(recompute);
   return MMST_OK;
@@ -82,7 +82,7 @@ int mmst_ffn_wgrad_config(int recompute) {
 int mmst_ffn_wgrad_mode(void) { return ffn_wgrad_recompute(); }
 
 // attention backward of self-attention in one pass: bit 0 = head_dim 32, bit 1 = head_dim 8, bit 2 = head_dim 8 with a
-// causal mask; 0 = the two passes (dQ, then dK/dV) everywhere; negative: the default (1, or what MMST_ATTN_BWD_MERGED says)
+// causal mask; 0 = the two passes (dQ, then dK/dV) everywhere; negative: the default (0, or what MMST_ATTN_BWD_MERGED says)
 int mmst_attn_bwd_config(int mode) {
   attn_set_bwd_merged(mode);
   return MMST_OK;

@@ -1073,19 +1073,20 @@ namespace {
 // The single-pass kernel serves self-attention (causal only with head_dim 8) whose tiled rows fit its dQ array
 // (head_dim 8: at most 128 rows beside the tail rows; head_dim 32: at most 608).  Setting (attn_set_bwd_merged, or
 // the environment variable MMST_ATTN_BWD_MERGED): bit 0 = use it for head_dim 32, bit 1 = for head_dim 8, bit 2 = for
-// head_dim 8 with a causal mask (the decoder's self-attention; the causal form walks every tile and masks inside:
-// measured 0.02 ms slower per training step than the two 14 us launches it replaces); 0 = the two-pass form
-// everywhere.  Default 1.  Measured at 64 molecules, alone on the GPU: head_dim 32 (582 rows) 128 us
-// against 173 us for the two passes, head_dim 8 (3 x 129 + 66 rows) 111 us against 109 us (its workgroups need 150 KiB
-// of LDS for eight waves).  Inside a training step the head_dim 32 kernel is time-neutral: its 158 KiB of LDS keep
-// it off a CU while a feed-forward weight-gradient workgroup of the other stream (82 KiB) is resident, so the two
-// run one after the other where the two-pass kernels (70 KiB, 128 registers) ran beside it.
+// head_dim 8 with a causal mask (the decoder's self-attention; the causal form walks every tile and masks inside);
+// 0 = the two-pass form everywhere, the default.  Measured at 64 molecules, alone on the GPU: head_dim 32 (582 rows)
+// 128 us against 173 us for the two passes; head_dim 8 (3 x 129 + 66 rows) 111 us against 109 us (its workgroups need
+// 150 KiB of LDS for eight waves).  Inside a training step, where the attention backward shares the GPU with the
+// feed-forward weight-gradient kernel of the second stream, the single-pass kernels lose: their 150-158 KiB of LDS keep
+// them off a CU while a weight-gradient workgroup (82 KiB) is resident, so the two run one after the other where the
+// two-pass kernels (70 KiB, 128 registers) run beside it: 7.44 ms per step with bit 0 set against 7.38 ms without,
+// +0.02 ms for bit 2.  Callers whose backward runs alone (no second stream) gain the difference measured alone.
 int g_bwd_merged = -1;
 int bwd_merged_mode() {
   if (g_bwd_merged < 0) {
     const char* e = getenv("MMST_ATTN_BWD_MERGED");
-    const int v = e ? atoi(e) : 1;
-    g_bwd_merged = (v >= 0 && v <= 7) ? v : 1;
+    const int v = e ? atoi(e) : 0;
+    g_bwd_merged = (v >= 0 && v <= 7) ? v : 0;
   }
   return g_bwd_merged;
 }
