@@ -21,6 +21,9 @@ namespace {
 #ifndef MMST_DEC_SKIP   // measurement builds only: bit 0 self-attention, bit 1 cross-attention, bit 2 feed-forward left out
 #define MMST_DEC_SKIP 0
 #endif
+#ifndef MMST_DEC_STREAM_KV   // measurement builds: 0 = default cache policy for the memory keys/values
+#define MMST_DEC_STREAM_KV 1
+#endif
 #ifndef MMST_DECODE_SHARED_CROSS
 #define MMST_DECODE_SHARED_CROSS 1
 #endif
@@ -319,7 +322,10 @@ __device__ __forceinline__ void merge_softmax(Smem<R>& sm, float m, float l, flo
 // from).  Lane = (key slot, head): 16 lanes read one key's 256-byte row, a wave covers 4 keys per step, the
 // workgroup 64.  If last_k != nullptr (Q == 1 only), key nkeys-1 is read from LDS instead (the row this workgroup
 // has just produced).  Results -> out + r*D (bf16-rounded).
-template <int R, int Q>
+// STREAM: the keys/values are read once per launch by this workgroup only (the projected encoder memory): they are
+// loaded with the non-temporal hint, so that they do not push the decoder weights, which every workgroup of the XCD
+// reads, out of its L2.
+template <int R, int Q, bool STREAM = false>
 __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
                                        int nkeys, const float* kbias, const float* last_k, const float* last_v,
                                        const int32_t* slot_of, int cap, bf16* out, int tid) {
@@ -348,8 +354,13 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
     for (int u = 0; u < U; ++u) {
       const int key = min(k0 + u * STEP, nkeys - 1);
       const size_t row = slot_of ? (size_t)slot_of[key] * cap + key : (size_t)key;
-      kt[u] = *reinterpret_cast<const bf16x8*>(kbase + row * ld + hh * HD);
-      vt[u] = *reinterpret_cast<const bf16x8*>(vbase + row * ld + hh * HD);
+      if (STREAM) {
+        kt[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kbase + row * ld + hh * HD));
+        vt[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vbase + row * ld + hh * HD));
+      } else {
+        kt[u] = *reinterpret_cast<const bf16x8*>(kbase + row * ld + hh * HD);
+        vt[u] = *reinterpret_cast<const bf16x8*>(vbase + row * ld + hh * HD);
+      }
       kb[u] = kbias ? kbias[key] * LOG2E : 0.f;
     }
     if (Q == 1 && last_k) {
@@ -428,8 +439,8 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     for (int r = 0; r < ((MMST_DEC_SKIP & 1) ? 0 : R); ++r) {
       const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
       const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
-      attend<R, 1>(sm, sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist,
-                   s.cap, sm.vattn[r], tid);
+      attend<R, 1, (MMST_DEC_STREAM_KV & 2) != 0>(sm, sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv[r] + D,
+                                                  sm.qkv[r] + 2 * D, hist, s.cap, sm.vattn[r], tid);
     }
     // 3. out_proj + residual + norm1
     project_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], tid,
@@ -445,7 +456,8 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
 #if MMST_DEC_SKIP & 2
 #elif MMST_DECODE_SHARED_CROSS
-    attend<R, R>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0, &sm.vattn[0][0], tid);
+    attend<R, R, (MMST_DEC_STREAM_KV & 1) != 0>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0,
+                                          &sm.vattn[0][0], tid);
 #else
 #pragma unroll
     for (int r = 0; r < R; ++r)
