@@ -172,7 +172,8 @@ class DecStackStep(C.Structure):
         "mem_bias", "w_out", "b_out", "logits") + [("ld_logits", C.c_int), ("n_out", C.c_int)] + _ptrs(
         "next_tok", "next_prob") + [("temperature", C.c_float), ("V", C.c_int),
                                     ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int),
-                                    ("kv_group", C.c_int), ("rows_per_group", C.c_int), ("hist", C.c_void_p)]
+                                    ("kv_group", C.c_int), ("rows_per_group", C.c_int), ("hist", C.c_void_p),
+                                    ("ffn_ws", C.c_void_p)]
 
 
 class DecBwd(C.Structure):

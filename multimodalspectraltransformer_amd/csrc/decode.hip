@@ -14,6 +14,7 @@
 // accumulation, fp32 softmax and LayerNorm statistics); only the summation order differs.
 #include "../../include/mmst.h"
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -35,7 +36,17 @@ struct StackArgs {
   mmst_dec_params p[MMST_MAX_DEC_LAYERS];
   mmst_dec_stack_step s;
   int n_layers;
+  // Split token step (mmst_dec_stack_step.ffn_ws given): a launch runs layers [l_begin, l_end).  MODE_PRO: its input rows
+  // are the output of layer l_begin - 1, whose feed-forward block ran as a launch of its own (decode_ffn_kernel): sum of
+  // its hidden-slice partials + bias + residual, then norm3.  MODE_SPLIT: the launch stops behind norm2 of layer
+  // l_begin and hands the rows to that kernel.
+  int l_begin, l_end, mode;
 };
+enum { MODE_PRO = 1, MODE_SPLIT = 2 };
+constexpr int FFN_HS = 16;   // hidden slices of the token-batched feed-forward kernel (128 hidden columns each)
+// workspace of the split token step: bf16 rows [B][128] (the feed-forward input), then fp32 partials [FFN_HS][B][128]
+__device__ __forceinline__ bf16* ws_rows(void* ws) { return (bf16*)ws; }
+__device__ __forceinline__ float* ws_slabs(void* ws, int B) { return (float*)((char*)ws + (((size_t)B * D * 2 + 255) & ~(size_t)255)); }
 
 // R = sequences per workgroup.  R > 1: the workgroup owns the R sequences (beams) of ONE molecule; every weight row
 // it streams serves R rows, and the molecule's projected memory keys/values are read once for all of them.
@@ -406,8 +417,24 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   const int tid = threadIdx.x, g = blockIdx.x;
   const int b0 = g * R;               // first sequence of this workgroup
   const int pos = s.pos;
-  // input rows: given, or embedding of the token + positional row
-  if (tid < R * D) {
+  if (args.mode & MODE_PRO) {
+    // input rows = norm3(x2 + b2 + sum of the feed-forward partials) of the layer in front
+    const mmst_dec_params& pp = args.p[args.l_begin - 1];
+    float z = 0.f;
+    if (tid < R * D) {
+      const int r = tid >> 7, c = tid & (D - 1);
+      const size_t row = (size_t)(b0 + r);
+      const float* slab = ws_slabs(s.ffn_ws, s.B) + row * D + c;
+      float part[FFN_HS];
+#pragma unroll
+      for (int hs = 0; hs < FFN_HS; ++hs) part[hs] = slab[(size_t)hs * s.B * D];
+      z = pp.b_2[c] + (float)ws_rows(s.ffn_ws)[row * D + c];
+#pragma unroll
+      for (int hs = 0; hs < FFN_HS; ++hs) z += part[hs];
+    }
+    layernorm_rows<R>(sm, z, pp.g3, pp.be3, sm.x, sm.vx, tid);
+  } else if (tid < R * D) {
+    // input rows: given, or embedding of the token + positional row
     const int r = tid >> 7, c = tid & (D - 1);
     bf16 v;
     if (s.tok) {
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   lds_barrier();
   const int bm = R > 1 ? g : b0 / s.kv_group;   // row block of the encoder memory these sequences read
   const float* mbias = s.mem_bias ? s.mem_bias + (size_t)bm * s.L : nullptr;
-  for (int l = 0; l < args.n_layers; ++l) {
+  for (int l = args.l_begin; l < args.l_end; ++l) {
     const mmst_dec_params& p = args.p[l];
     bf16* cache = (bf16*)s.qkv_cache[l] + (size_t)b0 * s.cap * 3 * D;   // caches of this workgroup's sequences
     // 1. Q|K|V of the new position, appended to each sequence's own cache
@@ -469,6 +496,10 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     lds_barrier();
     z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
     layernorm_rows<R>(sm, z, p.g2, p.be2, sm.x2, sm.vx, tid);
+    if (args.mode & MODE_SPLIT) {   // the feed-forward block of this layer is the next launch
+      if (tid < R * D) ws_rows(s.ffn_ws)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
+      return;
+    }
     // 7. feed-forward block + norm3
     if (!(MMST_DEC_SKIP & 4)) {
       project_k128<R, FF, 8>((const bf16*)p.w_1, p.b_1, &sm.vx[0][0], tid,
@@ -513,9 +544,111 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   }
 }
 
+// Feed-forward block of ONE decoder layer for all sequences of a token step (without bias2, residual and norm3, which
+// the next launch applies): partial[hs][row][n] = sum over hidden slice hs of relu(x W1^T + b1)[row][j] W2[n][j].
+// Grid = (64-row tiles, FFN_HS hidden slices of 128 columns); a wave owns 16 rows.  The slice's weights (128 rows of
+// linear1, 128 columns of linear2: 64 KiB of the 1 MiB a layer's block weighs; the per-sequence kernel streams the whole
+// MiB through every workgroup) come in by LDS-DMA, all 64 requests of a lane in flight at once, as [128][16 chunks of
+// 16 B] images whose chunk index is XORed with the row (conflict-free fragment reads; the swizzle is applied to the
+// source address, the DMA destination being lane-linear).  Both GEMMs are v_mfma_f32_16x16x32_bf16 with the WEIGHTS
+// as the A operand and the rows as the B operand.  The first GEMM leaves lane (row, q) with hidden columns
+// 16 t + 4 q + i of tile t; two tiles side by side are the 8 contraction entries of the second GEMM's B operand, and
+// its weight fragments are read in that order (two 8-byte pieces per lane).
+typedef const __attribute__((address_space(1))) void* dec_gptr_t;
+typedef __attribute__((address_space(3))) void* dec_lptr_t;
+__global__ __launch_bounds__(256) void decode_ffn_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W1,
+                                                         const float* __restrict__ b1, const bf16* __restrict__ W2,
+                                                         float* __restrict__ slabs, int rows, int Bcap) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 32768];
+  unsigned char* w1img = smem;            // [128 hidden rows][256 B]: row r, logical chunk c at position c ^ (r & 15)
+  unsigned char* w2img = smem + 32768;    // [128 output rows][256 B of this slice's hidden columns], same swizzle
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int hs = blockIdx.y, m0 = ((int)blockIdx.x * 4 + wave) * 16;
+  // 32 DMA instructions per image over the 4 waves: instruction i of a wave fills rows 4 (8 wave + i) .. + 3
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 4 * (8 * wave + i) + (lane >> 4), pos = lane & 15, c = pos ^ (r & 15);
+    __builtin_amdgcn_global_load_lds((dec_gptr_t)(W1 + (size_t)(hs * 128 + r) * D + c * 8),
+                                     (dec_lptr_t)(w1img + (8 * wave + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((dec_gptr_t)(W2 + (size_t)r * FF + hs * 128 + c * 8),
+                                     (dec_lptr_t)(w2img + (8 * wave + i) * 1024), 16, 0, 0);
+  }
+  const int m = m0 + j;
+  bf16x8 xf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    xf[ks] = bf16x8{};
+    if (m < rows) xf[ks] = *reinterpret_cast<const bf16x8*>(X + (size_t)m * D + ks * 32 + q * 8);
+  }
+  f32x4 bb[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bb[t] = *reinterpret_cast<const f32x4*>(b1 + hs * 128 + t * 16 + 4 * q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (m0 >= rows) return;
+  bf16x8 hf[4];   // the hidden slice as B fragments: hf[p] = columns 32 p + 4 q + {0..3} and 32 p + 16 + 4 q + {0..3}
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    f32x4 a[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * pp + u, r = 16 * t + j;
+      a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1img + r * 256 + (((ks * 4 + q) ^ (r & 15)) << 4));
+        a[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[ks], a[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[u][i] = fmaxf(a[u][i] + bb[t][i], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hf[pp][i] = (bf16)a[0][i]; hf[pp][4 + i] = (bf16)a[1][i]; }
+  }
+  float* out = slabs + ((size_t)hs * Bcap + m) * D + 4 * q;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = 16 * t + j;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      // hidden columns 32 pp + 4 q + {0..3} and 32 pp + 16 + 4 q + {0..3} of this slice: halves of chunks 4 pp + (q >> 1)
+      // and 4 pp + 2 + (q >> 1)
+      const int c0 = 4 * pp + (q >> 1), c1 = c0 + 2, hb = (q & 1) * 8;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(w2img + r * 256 + ((c0 ^ (r & 15)) << 4) + hb);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(w2img + r * 256 + ((c1 ^ (r & 15)) << 4) + hb);
+      const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[pp], acc, 0, 0, 0);
+    }
+    if (m < rows) *reinterpret_cast<f32x4*>(out + t * 16) = acc;   // columns 16 t + 4 q + i of row m
+  }
+}
+
+template <int R>
+void launch_stack(const StackArgs& a, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(decode_stack_kernel<R>, dim3(B / R), dim3(NT), 0, stream, a);
+}
+
+}  // namespace
+
+namespace {
+int g_split_min = -1;
+int decode_split_min() {
+  if (g_split_min < 0) {
+    const char* e = getenv("MMST_DECODE_SPLIT_FFN");
+    g_split_min = e ? atoi(e) : 256;
+    if (g_split_min < 0) g_split_min = 256;
+  }
+  return g_split_min;
+}
 }  // namespace
 
 extern "C" int mmst_sizeof_dec_stack_step() { return (int)sizeof(mmst_dec_stack_step); }
+// least number of sequences from which mmst_decoder_stack_step takes the split form (0 = never, negative = default)
+extern "C" int mmst_decoder_stack_config(int split_min_sequences) {
+  g_split_min = split_min_sequences;
+  return MMST_OK;
+}
 
 extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, const mmst_dec_stack_step* s, int nhead,
                                        void* stream) {
@@ -537,14 +670,36 @@ extern "C" int mmst_decoder_stack_step(int n_layers, const mmst_dec_params* p, c
   a.s = *s;
   if (a.s.kv_group < 1) a.s.kv_group = 1;
   a.n_layers = n_layers;
+  a.l_begin = 0; a.l_end = n_layers; a.mode = 0;
   // the beams of a molecule (kv_group of 2..4 sequences) share one workgroup; otherwise one workgroup per sequence
   const int R = (a.s.kv_group >= 2 && a.s.kv_group <= 4 && a.s.rows_per_group != 1) ? a.s.kv_group : 1;
   if (a.s.hist && R != a.s.kv_group) return MMST_ERR_ARG;
-  switch (R) {
-    case 1: hipLaunchKernelGGL(decode_stack_kernel<1>, dim3(s->B), dim3(NT), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(decode_stack_kernel<2>, dim3(s->B / 2), dim3(NT), 0, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(decode_stack_kernel<3>, dim3(s->B / 3), dim3(NT), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(decode_stack_kernel<4>, dim3(s->B / 4), dim3(NT), 0, (hipStream_t)stream, a); break;
+  hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](const StackArgs& x) {
+    switch (R) {
+      case 1: launch_stack<1>(x, s->B, st); break;
+      case 2: launch_stack<2>(x, s->B, st); break;
+      case 3: launch_stack<3>(x, s->B, st); break;
+      default: launch_stack<4>(x, s->B, st); break;
+    }
+  };
+  // Split token step: per layer one launch of the per-sequence kernel up to norm2 and one of the token-batched
+  // feed-forward kernel, which reads a layer's feed-forward weights once per token step instead of once per workgroup.
+  // Taken when the caller provides the workspace and there are enough sequences for it to pay (mmst_decoder_stack_config, or
+  // MMST_DECODE_SPLIT_FFN: the least number of sequences, default 256; 0 = never).
+  const int split_min = decode_split_min();
+  if (s->ffn_ws && split_min > 0 && s->B >= split_min) {
+    for (int l = 0; l < n_layers; ++l) {
+      a.l_begin = l; a.l_end = l + 1; a.mode = MODE_SPLIT | (l > 0 ? MODE_PRO : 0);
+      launch(a);
+      hipLaunchKernelGGL(decode_ffn_kernel, dim3((s->B + 63) / 64, FFN_HS), dim3(256), 0, st,
+                         (const bf16*)s->ffn_ws, (const bf16*)p[l].w_1, p[l].b_1, (const bf16*)p[l].w_2,
+                         (float*)((char*)s->ffn_ws + (((size_t)s->B * D * 2 + 255) & ~(size_t)255)), s->B, s->B);
+    }
+    a.l_begin = a.l_end = n_layers; a.mode = MODE_PRO;
+    launch(a);
+  } else {
+    launch(a);
   }
   MMST_CHECK_LAUNCH();
   return MMST_OK;

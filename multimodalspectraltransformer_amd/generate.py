@@ -91,6 +91,9 @@ class _StepState:
         ss.logits, ss.ld_logits, ss.n_out = self.logits.data_ptr(), VPAD, VPAD
         ss.V = model.out_size
         ss.B, ss.pos, ss.cap, ss.L = B, 0, cap, pl.Lmem
+        # workspace of the split token step (MMST_DEC_STACK_WS_BYTES): bf16 rows, then 16 fp32 partial slabs
+        self.stack_ws = torch.zeros(((B * D * 2 + 255) // 256 * 256 + 16 * B * D * 4 + 3) // 4, dtype=torch.float32, device=dev)
+        ss.ffn_ws = self.stack_ws.data_ptr()
         self.ndl = ndl
         self.ops = ops
         self.graphs = {}   # (position, temperature) -> captured token step

@@ -86,8 +86,20 @@ def _params_array(layers):
     (8, 4, 200, 64, 33, 2, False),    # four beams per molecule
     (1, 1, 9, 200, 131, 1, False),    # more cached positions than one batch of key loads covers
     (64, 1, 130, 64, 17, 6, True),
+    (70, 1, 90, 32, 9, 2, True),      # a ragged last 64-row tile of the token-batched feed-forward launch
 ])
-def test_stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked):
+@pytest.mark.parametrize("split", [False, True], ids=["one-launch", "split-ffn"])
+def test_stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked, split):
+    """split-ffn: the form taken from 256 sequences on when the caller gives the workspace (every layer's feed-forward
+    block as a launch of its own over all sequences), forced here for the small batches."""
+    L.check(L.lib().mmst_decoder_stack_config(1 if split else 0), "mmst_decoder_stack_config")
+    try:
+        _stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked, split)
+    finally:
+        L.check(L.lib().mmst_decoder_stack_config(-1), "mmst_decoder_stack_config")
+
+
+def _stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked, split):
     dev = "cuda"
     gen = torch.Generator(device=dev).manual_seed(1000 + B + pos)
     layers = [_layer_params(gen, dev) for _ in range(nl)]
@@ -124,8 +136,11 @@ def test_stack_step_vs_torch(B, group, Lm, cap, pos, nl, masked):
     s.w_out, s.b_out, s.logits, s.ld_logits, s.n_out = w_out.data_ptr(), b_out.data_ptr(), logits.data_ptr(), VP, VP
     s.next_tok, s.next_prob, s.temperature, s.V = nxt.data_ptr(), prob.data_ptr(), 0.7, V
     s.B, s.pos, s.cap, s.L, s.kv_group = B, pos, cap, Lm, group
+    ws = torch.full((((B * D * 2 + 255) // 256 * 256 + 16 * B * D * 4) // 4,), float("nan"), device=dev)   # MMST_DEC_STACK_WS_BYTES
+    s.ffn_ws = ws.data_ptr() if split else None
     L.check(L.lib().mmst_decoder_stack_step(nl, _params_array(layers), C.byref(s), NH, L.stream_ptr()), "stack_step")
     torch.cuda.synchronize()
+    assert bool(torch.isnan(ws).all()) != split     # the workspace is used by the split form only
 
     got = y.float()
     assert float((got - want).abs().max()) < 6e-2
