@@ -25,6 +25,9 @@ namespace {
 #ifndef MMST_DEC_STREAM_KV   // measurement builds: 0 = default cache policy for the memory keys/values
 #define MMST_DEC_STREAM_KV 1
 #endif
+#ifndef MMST_DEC_CROSS_U     // measurement builds: keys in flight per lane in the cross-attention of the split form's
+#define MMST_DEC_CROSS_U 0   // launches (0 = as everywhere: 2 for three or more queries; 3 measured equal, 4 slower)
+#endif
 #ifndef MMST_DECODE_SHARED_CROSS
 #define MMST_DECODE_SHARED_CROSS 1
 #endif
@@ -336,7 +339,7 @@ __device__ __forceinline__ void merge_softmax(Smem<R>& sm, float m, float l, flo
 // STREAM: the keys/values are read once per launch by this workgroup only (the projected encoder memory): they are
 // loaded with the non-temporal hint, so that they do not push the decoder weights, which every workgroup of the XCD
 // reads, out of its L2.
-template <int R, int Q, bool STREAM = false>
+template <int R, int Q, bool STREAM = false, int UU = 0>
 __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
                                        int nkeys, const float* kbias, const float* last_k, const float* last_v,
                                        const int32_t* slot_of, int cap, bf16* out, int tid) {
@@ -356,7 +359,7 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
 #pragma unroll
     for (int d = 0; d < HD; ++d) acc[r][d] = 0.f;
   }
-  constexpr int U = Q > 2 ? 2 : 4, STEP = 4 * NWAVE;
+  constexpr int U = UU > 0 ? UU : (Q > 2 ? 2 : 4), STEP = 4 * NWAVE;   // keys in flight per lane
 #pragma unroll 1
   for (int k0 = slot; k0 < nkeys; k0 += U * STEP) {
     bf16x8 kt[U], vt[U];
@@ -410,7 +413,8 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
   for (int r = 0; r < Q; ++r) merge_softmax<R>(sm, m[r], l[r], acc[r], out + r * D, tid);
 }
 
-template <int R>
+// SPLIT: an instance for the launches of the split token step that stop behind norm2 (no feed-forward code in it)
+template <int R, bool SPLIT = false>
 __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) {
   __shared__ Smem<R> sm;
   const mmst_dec_stack_step& s = args.s;
@@ -483,8 +487,8 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
 #if MMST_DEC_SKIP & 2
 #elif MMST_DECODE_SHARED_CROSS
-    attend<R, R, (MMST_DEC_STREAM_KV & 1) != 0>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0,
-                                          &sm.vattn[0][0], tid);
+    attend<R, R, (MMST_DEC_STREAM_KV & 1) != 0, (SPLIT ? MMST_DEC_CROSS_U : 0)>(sm, &sm.qc[0][0], D, kv, kv + D, 2 * D, s.L, mbias,
+                                                                          nullptr, nullptr, nullptr, 0, &sm.vattn[0][0], tid);
 #else
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -496,11 +500,12 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     lds_barrier();
     z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
     layernorm_rows<R>(sm, z, p.g2, p.be2, sm.x2, sm.vx, tid);
-    if (args.mode & MODE_SPLIT) {   // the feed-forward block of this layer is the next launch
+    if constexpr (SPLIT) {   // the feed-forward block of this layer is the next launch
       if (tid < R * D) ws_rows(s.ffn_ws)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
       return;
     }
     // 7. feed-forward block + norm3
+    if constexpr (!SPLIT) {
     if (!(MMST_DEC_SKIP & 4)) {
       project_k128<R, FF, 8>((const bf16*)p.w_1, p.b_1, &sm.vx[0][0], tid,
                              [&](int r, int n, float v) { sm.vh[r][n] = (bf16)fmaxf(v, 0.f); });
@@ -519,7 +524,9 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
       z = sm.w2part[0][r][c] + sm.w2part[1][r][c] + p.b_2[c] + sm.x2[r][c];
     }
     layernorm_rows<R>(sm, z, p.g3, p.be3, sm.x, sm.vx, tid);
+    }
   }
+  if constexpr (SPLIT) return;
   if (s.y && tid < R * D) ((bf16*)s.y)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
   if (!s.logits) return;
   // vocabulary projection (weight rows beyond the vocabulary are zero padding of the caller's matrix)
@@ -626,7 +633,8 @@ __global__ __launch_bounds__(256) void decode_ffn_kernel(const bf16* __restrict_
 
 template <int R>
 void launch_stack(const StackArgs& a, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(decode_stack_kernel<R>, dim3(B / R), dim3(NT), 0, stream, a);
+  if (a.mode & MODE_SPLIT) hipLaunchKernelGGL((decode_stack_kernel<R, true>), dim3(B / R), dim3(NT), 0, stream, a);
+  else hipLaunchKernelGGL((decode_stack_kernel<R, false>), dim3(B / R), dim3(NT), 0, stream, a);
 }
 
 }  // namespace
