@@ -67,7 +67,7 @@ struct Smem {
   __attribute__((aligned(16))) bf16 vattn[R][D];
   __attribute__((aligned(16))) bf16 vh[R][FF];
   float w2part[2][R][D];           // the two contraction halves of the second feed-forward projection
-  float part[NWAVE][NH][HD + 2];   // per-wave softmax partials: m, l, acc[8]
+  float part[R][NWAVE][NH][HD + 2];   // per-query, per-wave softmax partials: m, l, acc[8]
   float red[2][NWAVE];
 };
 
@@ -289,43 +289,48 @@ __device__ __forceinline__ void layernorm_rows(Smem<R>& sm, float z, const float
   lds_barrier();
 }
 
-// merge of the per-lane online-softmax states (m, l, acc[8]) of one query row: the 4 key slots of a wave (lanes with
-// equal head), then the waves through LDS; result -> out[0..128) (bf16-rounded)
-template <int R>
-__device__ __forceinline__ void merge_softmax(Smem<R>& sm, float m, float l, float (&acc)[HD], bf16* out, int tid) {
+// merge of the per-lane online-softmax states (m, l, acc[8]) of Q query rows at once: the 4 key slots of a wave (lanes
+// with equal head), then the waves through LDS (two barriers for all the rows); results -> out + r*D (bf16-rounded)
+template <int R, int Q>
+__device__ __forceinline__ void merge_softmax_all(Smem<R>& sm, float (&m)[Q], float (&l)[Q], float (&acc)[Q][HD], bf16* out,
+                                                  int tid) {
+  static_assert(Q <= R, "one partial array per sequence of the workgroup");
   const int lane = tid & 63, wave = tid >> 6, hh = lane & 15;
-  float M = fmaxf(m, __shfl_xor(m, 16));
-  M = fmaxf(M, __shfl_xor(M, 32));
-  const float f = __builtin_amdgcn_exp2f(m - M);
-  l *= f;
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
 #pragma unroll
-  for (int d = 0; d < HD; ++d) {
-    acc[d] *= f;
-    acc[d] += __shfl_xor(acc[d], 16);
-    acc[d] += __shfl_xor(acc[d], 32);
-  }
-  if (lane < NH) {
-    sm.part[wave][hh][0] = M;
-    sm.part[wave][hh][1] = l;
+  for (int r = 0; r < Q; ++r) {
+    float M = fmaxf(m[r], __shfl_xor(m[r], 16));
+    M = fmaxf(M, __shfl_xor(M, 32));
+    const float f = __builtin_amdgcn_exp2f(m[r] - M);
+    float lr = l[r] * f;
+    lr += __shfl_xor(lr, 16);
+    lr += __shfl_xor(lr, 32);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) sm.part[wave][hh][2 + d] = acc[d];
+    for (int d = 0; d < HD; ++d) {
+      acc[r][d] *= f;
+      acc[r][d] += __shfl_xor(acc[r][d], 16);
+      acc[r][d] += __shfl_xor(acc[r][d], 32);
+    }
+    if (lane < NH) {
+      sm.part[r][wave][hh][0] = M;
+      sm.part[r][wave][hh][1] = lr;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sm.part[r][wave][hh][2 + d] = acc[r][d];
+    }
   }
   lds_barrier();
-  if (tid < D) {
-    const int h2 = tid >> 3, d = tid & 7;
+  if (tid < Q * D) {
+    const int r = tid >> 7, c = tid & (D - 1), h2 = c >> 3, d = c & 7;
     float MM = NEG_BIG;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) MM = fmaxf(MM, sm.part[w][h2][0]);
+    for (int w = 0; w < NWAVE; ++w) MM = fmaxf(MM, sm.part[r][w][h2][0]);
     float L = 0.f, A = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) {
-      const float g = __builtin_amdgcn_exp2f(sm.part[w][h2][0] - MM);
-      L += sm.part[w][h2][1] * g;
-      A += sm.part[w][h2][2 + d] * g;
+      const float g = __builtin_amdgcn_exp2f(sm.part[r][w][h2][0] - MM);
+      L += sm.part[r][w][h2][1] * g;
+      A += sm.part[r][w][h2][2 + d] * g;
     }
-    out[tid] = (bf16)(A * (L > 0.f ? 1.0f / L : 0.f));
+    out[r * D + c] = (bf16)(A * (L > 0.f ? 1.0f / L : 0.f));
   }
   lds_barrier();
 }
@@ -340,9 +345,10 @@ __device__ __forceinline__ void merge_softmax(Smem<R>& sm, float m, float l, flo
 // loaded with the non-temporal hint, so that they do not push the decoder weights, which every workgroup of the XCD
 // reads, out of its L2.
 template <int R, int Q, bool STREAM = false, int UU = 0>
-__device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
-                                       int nkeys, const float* kbias, const float* last_k, const float* last_v,
-                                       const int32_t* slot_of, int cap, bf16* out, int tid) {
+__device__ __forceinline__ void attend_scores(const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
+                                              int nkeys, const float* kbias, const float* last_k, const float* last_v,
+                                              const int32_t* slot_of, int cap, int tid, float (&m)[Q], float (&l)[Q],
+                                              float (&acc)[Q][HD]) {
   const int lane = tid & 63, wave = tid >> 6;
   const int hh = lane & 15, slot = wave * 4 + (lane >> 4);
   const float scale2 = rsqrtf((float)HD) * LOG2E;
@@ -351,7 +357,6 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
   for (int r = 0; r < Q; ++r)
 #pragma unroll
     for (int j = 0; j < 4; ++j) qv[r][j] = pack2(q[r * qstride + hh * HD + 2 * j], q[r * qstride + hh * HD + 2 * j + 1]);
-  float m[Q], l[Q], acc[Q][HD];
 #pragma unroll
   for (int r = 0; r < Q; ++r) {
     m[r] = NEG_BIG;
@@ -409,8 +414,14 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < Q; ++r) merge_softmax<R>(sm, m[r], l[r], acc[r], out + r * D, tid);
+}
+template <int R, int Q, bool STREAM = false, int UU = 0>
+__device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride, const bf16* kbase, const bf16* vbase, size_t ld,
+                                       int nkeys, const float* kbias, const float* last_k, const float* last_v,
+                                       const int32_t* slot_of, int cap, bf16* out, int tid) {
+  float m[Q], l[Q], acc[Q][HD];
+  attend_scores<R, Q, STREAM, UU>(q, qstride, kbase, vbase, ld, nkeys, kbias, last_k, last_v, slot_of, cap, tid, m, l, acc);
+  merge_softmax_all<R, Q>(sm, m, l, acc, out, tid);
 }
 
 // SPLIT: an instance for the launches of the split token step that stop behind norm2 (no feed-forward code in it)
@@ -466,12 +477,21 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     // 2. self-attention over positions 0..pos (every cached key is visible).  With a history table the key of position
     //    j is read from the cache of the sequence that produced it (slot hist[b][j] of this molecule); position `pos`
     //    itself is the row just computed.
+    if (!(MMST_DEC_SKIP & 1)) {   // the R sequences one after the other (their keys differ), their merges at once
+      float am[R], al[R], aacc[R][HD];
 #pragma unroll
-    for (int r = 0; r < ((MMST_DEC_SKIP & 1) ? 0 : R); ++r) {
-      const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
-      const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
-      attend<R, 1, (MMST_DEC_STREAM_KV & 2) != 0>(sm, sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr, sm.qkv[r] + D,
-                                                  sm.qkv[r] + 2 * D, hist, s.cap, sm.vattn[r], tid);
+      for (int r = 0; r < R; ++r) {
+        const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
+        const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
+        float m1[1], l1[1], a1[1][HD];
+        attend_scores<R, 1, (MMST_DEC_STREAM_KV & 2) != 0>(sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr,
+                                                           sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist, s.cap, tid, m1, l1, a1);
+        am[r] = m1[0];
+        al[r] = l1[0];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) aacc[r][d] = a1[0][d];
+      }
+      merge_softmax_all<R, R>(sm, am, al, aacc, &sm.vattn[0][0], tid);
     }
     // 3. out_proj + residual + norm1
     project_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], tid,
