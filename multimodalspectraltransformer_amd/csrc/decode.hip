@@ -479,17 +479,49 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     //    itself is the row just computed.
     if (!(MMST_DEC_SKIP & 1)) {   // the R sequences one after the other (their keys differ), their merges at once
       float am[R], al[R], aacc[R][HD];
+      if (R > 1 && pos + 1 <= 4 * NWAVE) {
+        // at most one key per lane: the key/value rows of ALL R sequences are requested before the first one is used
+        // (one round trip to the caches instead of R), the arithmetic is that of the general loop for a single key
+        const int lane = tid & 63, hh = lane & 15, key = (tid >> 6) * 4 + (lane >> 4);
+        const bool valid = key <= pos;
+        const float scale2 = rsqrtf((float)HD) * LOG2E;
+        bf16x8 kt[R], vt[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
-        const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
-        float m1[1], l1[1], a1[1][HD];
-        attend_scores<R, 1, (MMST_DEC_STREAM_KV & 2) != 0>(sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr,
-                                                           sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist, s.cap, tid, m1, l1, a1);
-        am[r] = m1[0];
-        al[r] = l1[0];
+        for (int r = 0; r < R; ++r) {
+          const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
+          const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
+          const int kk = valid ? key : pos;
+          const size_t row = hist ? (size_t)hist[kk] * s.cap + kk : (size_t)kk;
+          kt[r] = *reinterpret_cast<const bf16x8*>(base + D + row * 3 * D + hh * HD);
+          vt[r] = *reinterpret_cast<const bf16x8*>(base + 2 * D + row * 3 * D + hh * HD);
+        }
 #pragma unroll
-        for (int d = 0; d < HD; ++d) aacc[r][d] = a1[0][d];
+        for (int r = 0; r < R; ++r) {
+          if (key == pos) {   // the row this workgroup has just produced: not yet visible in memory
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { kt[r][d] = (bf16)sm.qkv[r][D + hh * HD + d]; vt[r][d] = (bf16)sm.qkv[r][2 * D + hh * HD + d]; }
+          }
+          bf16x2 qv[4];
+#pragma unroll
+          for (int jq = 0; jq < 4; ++jq) qv[jq] = pack2(sm.qkv[r][hh * HD + 2 * jq], sm.qkv[r][hh * HD + 2 * jq + 1]);
+          am[r] = valid ? dot8p(kt[r], qv, 0.f) * scale2 : NEG_BIG;
+          al[r] = valid ? 1.f : 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) aacc[r][d] = valid ? (float)vt[r][d] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int32_t* hist = s.hist ? s.hist + (size_t)(b0 + r) * s.cap : nullptr;
+          const bf16* base = hist ? cache : cache + (size_t)r * s.cap * 3 * D;
+          float m1[1], l1[1], a1[1][HD];
+          attend_scores<R, 1, (MMST_DEC_STREAM_KV & 2) != 0>(sm.qkv[r], 0, base + D, base + 2 * D, 3 * D, pos + 1, nullptr,
+                                                             sm.qkv[r] + D, sm.qkv[r] + 2 * D, hist, s.cap, tid, m1, l1, a1);
+          am[r] = m1[0];
+          al[r] = l1[0];
+#pragma unroll
+          for (int d = 0; d < HD; ++d) aacc[r][d] = a1[0][d];
+        }
       }
       merge_softmax_all<R, R>(sm, am, al, aacc, &sm.vattn[0][0], tid);
     }
