@@ -364,6 +364,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
   const float scale2 = scale * LOG2E;
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
+  const float inv_dscale = batch.drop_p > 0.f ? 1.0f - batch.drop_p : 1.0f, inv_scale2 = 1.0f / scale2;
   const bool dropping = batch.drop_p > 0.f;
   if (TAILS && tail_o > 0 && bc.blk == 0) {
     // the first workgroup of every (batch, head group) also serves the tail query rows, one head per wave
@@ -389,6 +390,11 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
       lse2 = pr.lse[(size_t)(b * H + hh) * Tq + q];
       if (h == 0) pr.delta[(size_t)(b * H + hh) * Tq + q] = delta;
     }
+    // Constant factors leave the per-score arithmetic: with keep in {0, 1} and c = 1/(1-p),
+    // dS = P (keep c dP - delta) scale = [P (keep dP - delta / c)] (c scale); the bracket is what the tiles accumulate,
+    // the factor is applied once to the output row.
+    delta *= inv_dscale;
+    lse2 = -lse2;
   }
 
   float m = NEG_BIG, l = 0.f;
@@ -419,7 +425,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
       stage_store<true, true>(kst, Kimg, Timg, tid);
       stage_store<true, false>(vst, Vimg, nullptr, tid);
     }
-    if (tid < KC) bias[tid] = bst;
+    if (tid < KC) bias[tid] = bst * inv_scale2;   // in score units: the accumulator of S starts from it
     __syncthreads();
     if (PREFETCH && c0 + KC < Sk_main) fetch(c0 + KC);
     if (!active) continue;
@@ -427,33 +433,37 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
     for (int t = 0; t < ntile; ++t) {
       const int lk0 = t * 32;
       if (CAUSAL && c0 + lk0 > q0 + 31) break;
-      f32x16 sacc = zero16();
+      // S accumulates on top of the key bias (read from LDS straight into the accumulator registers): the score in
+      // log2 units is sv * scale2, one FMA together with the subtraction of the row's maximum / log-sum-exp
+      f32x16 sacc;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 bb = *reinterpret_cast<const f32x4*>(bias + lk0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc[4 * g4 + j] = bb[j];
+      }
 #pragma unroll
       for (int s = 0; s < C::KS; ++s)
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Kimg, lk0 + r, s, h, hoff), qf[s], sacc, 0, 0, 0);
       float sv[16];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 bb = *reinterpret_cast<const f32x4*>(bias + lk0 + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = sacc[4 * g4 + j] * scale2 + bb[j];
-          if (CAUSAL && (c0 + lk0 + 8 * g4 + 4 * h + j) > q) v = -INFINITY;
-          sv[4 * g4 + j] = v;
-        }
+      for (int i = 0; i < 16; ++i) {
+        float v = sacc[i];
+        if (CAUSAL && (c0 + lk0 + acc_row(i, h)) > q) v = -INFINITY;
+        sv[i] = v;
       }
       float pv[16];
       if (!BWD) {
         float tmax = sv[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sv[i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale2;
         const float mn = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
         float ps = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { pv[i] = __builtin_amdgcn_exp2f(sv[i] - mn); ps += pv[i]; }
+        for (int i = 0; i < 16; ++i) { pv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], scale2, -mn)); ps += pv[i]; }
         l = l * alpha + ps;
 #pragma unroll
         for (int i = 0; i < C::OREGS; ++i) oacc[i] *= alpha;
@@ -474,15 +484,14 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
         const uint32_t tbase = rseed + (uint32_t)((c0 + lk0) >> 1) * ATTN_PAIR_MUL + (uint32_t)(2 * h) * ATTN_PAIR_MUL;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-          float p0 = __builtin_amdgcn_exp2f(sv[i] - lse2), p1 = __builtin_amdgcn_exp2f(sv[i + 1] - lse2);
-          float d0 = dpacc[i], d1 = dpacc[i + 1];
-          if (dropping) {
-            uint32_t hb = attn_pair_bits(tbase, (uint32_t)(acc_row(i, 0) >> 1) * ATTN_PAIR_MUL);
-            d0 = ((hb & 0xFFFFu) >= thr) ? d0 * dscale : 0.f;
-            d1 = ((hb >> 16) >= thr) ? d1 * dscale : 0.f;
-          }
-          pv[i] = p0 * (d0 - delta) * scale;
-          pv[i + 1] = p1 * (d1 - delta) * scale;
+          float p0 = __builtin_amdgcn_exp2f(fmaf(sv[i], scale2, lse2)), p1 = __builtin_amdgcn_exp2f(fmaf(sv[i + 1], scale2, lse2));
+          // no branch on `dropping` inside the tile (it would fence the instruction schedule at every pair): without
+          // dropout the threshold is 0 and every comparison keeps
+          const uint32_t hb = attn_pair_bits(tbase, (uint32_t)(acc_row(i, 0) >> 1) * ATTN_PAIR_MUL);
+          const float d0 = ((hb & 0xFFFFu) >= thr) ? dpacc[i] : 0.f;
+          const float d1 = ((hb >> 16) >= thr) ? dpacc[i + 1] : 0.f;
+          pv[i] = p0 * (d0 - delta);
+          pv[i + 1] = p1 * (d1 - delta);
         }
       }
       const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
@@ -513,10 +522,10 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) oacc[j] = oacc[j] * alpha + p * (float)(h ? vt[4 + j] : vt[j]);
       } else {
-        const float p = __builtin_amdgcn_exp2f(sc - lse2);
+        const float p = __builtin_amdgcn_exp2f(sc + lse2);
         float dp = dot8(dorow, vt);
-        dp = keep ? dp * dscale : 0.f;
-        const float ds = p * (dp - delta) * scale;
+        dp = keep ? dp : 0.f;
+        const float ds = p * (dp - delta);
 #pragma unroll
         for (int j = 0; j < 4; ++j) oacc[j] += ds * (float)(h ? kt[4 + j] : kt[j]);
       }
@@ -528,7 +537,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
     store_rows<HD>(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, oacc, inv, h);
     if (h == 0) pr.lse[(size_t)(b * H + hh) * Tq + q] = m + __builtin_amdgcn_logf(l);
   } else {
-    store_rows<HD>(pr.dQ + (size_t)(b * Tq + q) * pr.lddq + hh * HD, oacc, 1.0f, h);
+    store_rows<HD>(pr.dQ + (size_t)(b * Tq + q) * pr.lddq + hh * HD, oacc, scale * dscale, h);
   }
 }
 
@@ -576,6 +585,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
   const float scale2 = scale * LOG2E;
   const uint32_t thr = drop_threshold(batch.drop_p);
   const float dscale = batch.drop_p > 0.f ? 1.0f / (1.0f - batch.drop_p) : 1.0f;
+  const float inv_dscale = batch.drop_p > 0.f ? 1.0f - batch.drop_p : 1.0f, inv_scale2 = 1.0f / scale2;
   const bool dropping = batch.drop_p > 0.f;
   if (TAILS && tail_o > 0 && bc.blk == 0) {
     const TailCtx tc = {scale, scale2, dscale, thr, dropping};
@@ -606,8 +616,10 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
         dv = OWN_DELTA ? row_delta<HD>(pr, (size_t)b * Tq + c0 + i, bc.hg * C::HG + hj)
                        : pr.delta[(size_t)(b * H + bc.hg * C::HG + hj) * Tq + c0 + i];
       }
-      lse_all[j] = lv;
-      del_all[j] = dv;
+      // Staged in the form the tiles use (constant factors applied once to the output rows, see the dQ pass):
+      // -lse in score units is the start value of the S accumulator, delta comes divided by 1/(1-p)
+      lse_all[j] = -lv * inv_scale2;
+      del_all[j] = dv * inv_dscale;
       if (dropping) rs_all[j] = attn_row_seed(pr.seed, (uint32_t)((b * H + bc.hg * C::HG + hj) * Tq + c0 + i));
     }
     __syncthreads();
@@ -616,7 +628,13 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
     for (int t = 0; t < ntile; ++t) {
       const int lq0 = t * 32;
       if (CAUSAL && c0 + lq0 + 31 < k0) continue;  // every query of the tile precedes every key
-      f32x16 sacc = zero16(), dpacc = zero16();
+      f32x16 sacc, dpacc = zero16();
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 ll = *reinterpret_cast<const f32x4*>(lse_s + lq0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc[4 * g4 + j] = ll[j];
+      }
 #pragma unroll
       for (int s = 0; s < C::KS; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_rm<HD>(Qimg, lq0 + r, s, h, hoff), kf[s], sacc, 0, 0, 0);
@@ -625,7 +643,6 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
       float pd[16], ds[16];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 ll = *reinterpret_cast<const f32x4*>(lse_s + lq0 + 8 * g4 + 4 * h);
         f32x4 dd = *reinterpret_cast<const f32x4*>(del_s + lq0 + 8 * g4 + 4 * h);
         const uint4 rr = *reinterpret_cast<const uint4*>(rs_s + lq0 + 8 * g4 + 4 * h);
         const uint32_t rsv[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -633,20 +650,16 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
         for (int j = 0; j < 4; ++j) {
           const int i = 4 * g4 + j;
           const int qg = c0 + lq0 + 8 * g4 + 4 * h + j;
-          float v = sacc[i] * scale2 + bias2;
+          float v = fmaf(sacc[i], scale2, bias2);
           if (CAUSAL && key > qg) v = -INFINITY;
-          float p = __builtin_amdgcn_exp2f(v - ll[j]);
-          float d = dpacc[i];
-          float pk = p;
-          if (dropping) {
-            uint32_t hb = attn_pair_bits(rsv[j], pair_term);
-            bool keep = ((hb >> pair_shift) & 0xFFFFu) >= thr;
-            d = keep ? d * dscale : 0.f;
-            pk = keep ? p * dscale : 0.f;
-          }
+          const float p = __builtin_amdgcn_exp2f(v);
+          // (no branch on `dropping` here: threshold 0 keeps everything, whatever the seed words hold)
+          const uint32_t hb = attn_pair_bits(rsv[j], pair_term);
+          const float pk = ((hb >> pair_shift) & 0xFFFFu) >= thr ? p : 0.f;
           pd[i] = pk;
-          ds[i] = p * (d - dd[j]) * scale;
+          ds[i] = pk * dpacc[i] - p * dd[j];
         }
+        if (HD == 8) __builtin_amdgcn_sched_barrier(0);   // four scores at a time: hoisting every hash of the tile spills registers
       }
       const bf16x8 pf0 = pack8(pd), pf1 = pack8(pd + 8), sf0 = pack8(ds), sf1 = pack8(ds + 8);
       dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Dt, lq0, 0, lane, hoff), pf0, dvacc, 0, 0, 0);
@@ -666,14 +679,11 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
       const bf16x8 qrow = ldrow8(pr.Q + (size_t)(b * Tq + qt) * pr.ldq + hh * HD);
       const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * Tq + qt) * pr.lddo + hh * HD);
       const float p = __builtin_amdgcn_exp2f(dot8(krow, qrow) * scale2 + bias2 - pr.lse[stat]);
-      float dp = dot8(vrow, dorow), pk = p;
-      if (dropping) {
-        const bool keep = keep_of(attn_row_seed(pr.seed, (uint32_t)stat), key, thr);
-        dp = keep ? dp * dscale : 0.f;
-        pk = keep ? p * dscale : 0.f;
-      }
+      const float dp = dot8(vrow, dorow);
+      float pk = p;
+      if (dropping) pk = keep_of(attn_row_seed(pr.seed, (uint32_t)stat), key, thr) ? p : 0.f;
       const float dlt = OWN_DELTA ? dot8(dorow, ldrow8(pr.O + (size_t)(b * Tq + qt) * pr.ldo + hh * HD)) : pr.delta[stat];
-      const float ds = p * (dp - dlt) * scale;
+      const float ds = pk * dp - p * dlt * inv_dscale;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         dvacc[j] += pk * (float)(h ? dorow[4 + j] : dorow[j]);
@@ -681,8 +691,8 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
       }
     }
   }
-  store_rows<HD>(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dkacc, 1.0f, h);
-  store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, 1.0f, h);
+  store_rows<HD>(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dkacc, scale * dscale, h);
+  store_rows<HD>(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dvacc, dscale, h);
 }
 
 template <int HD, bool CAUSAL>
