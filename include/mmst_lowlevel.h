@@ -142,10 +142,12 @@ int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1, 2 or 3 */
 /* mmst_attn_bwd on self-attention (the encoder layers and the decoder's causal self-attention; torch call site
  * nn.MultiheadAttention backward): launches whose rows fit (head_dim 32: 608 rows; head_dim 8: 128 tiled rows) can
  * run ONE kernel that evaluates the probabilities once for dQ, dK and dV instead of two passes (dQ, then dK/dV).
- * Bits of `mode`: 0 = head_dim 32, 1 = head_dim 8 without a mask, 2 = head_dim 8 with the causal mask.  Default 0 (inside a training step the two passes share the GPU better with the second stream's kernels);
- * negative: back to the default.  Both forms give the same results to bf16 rounding. */
+ * Bits of `mode`: 0 = head_dim 32, 1 = head_dim 8 without a mask, 2 = head_dim 8 with the causal mask; bit 3 (8):
+ * head_dim 8 without a mask and at most 128 tiled rows runs both passes in one workgroup per (batch, 8 heads) that
+ * stages Q, K, V and dO once.  Default 0 (inside a training step the two passes share the GPU better with the second
+ * stream's kernels); negative: back to the default.  All forms give the same results to bf16 rounding. */
 int mmst_attn_bwd_config(int mode);
-int mmst_attn_bwd_mode(void);    /* the setting in force: 0..7 */
+int mmst_attn_bwd_mode(void);    /* the setting in force: 0..15 */
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */

@@ -82,7 +82,8 @@ int mmst_ffn_wgrad_config(int recompute) {
 int mmst_ffn_wgrad_mode(void) { return ffn_wgrad_recompute(); }
 
 // attention backward of self-attention in one pass: bit 0 = head_dim 32, bit 1 = head_dim 8, bit 2 = head_dim 8 with a
-// causal mask; 0 = the two passes (dQ, then dK/dV) everywhere; negative: the default (0, or what MMST_ATTN_BWD_MERGED says)
+// causal mask, bit 3 = both passes of a short head_dim 8 sequence in one workgroup; 0 = the two passes (dQ, then dK/dV)
+// everywhere; negative: the default (0, or what MMST_ATTN_BWD_MERGED says)
 int mmst_attn_bwd_config(int mode) {
   attn_set_bwd_merged(mode);
   return MMST_OK;

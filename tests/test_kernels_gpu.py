@@ -480,10 +480,11 @@ def run_attn(B, H, T, S, hd, causal, use_bias, p=0.0, seed=77, self_attn=True):
     close(gv.reshape(B, S, H, hd), vf.grad, rtol=3e-2, atol=3e-2)
 
 
-@pytest.fixture(params=[0, 7], ids=["bwd-two-pass", "bwd-one-pass"])
+@pytest.fixture(params=[0, 7, 8], ids=["bwd-two-pass", "bwd-one-pass", "bwd-short-seq"])
 def attn_bwd_mode(request):
-    """Both forms of the self-attention backward: two passes (dQ, then dK/dV) and the single-pass kernel (which serves
-    the shapes whose rows fit its LDS arrays; the others fall back to the two passes under either setting)."""
+    """The forms of the self-attention backward: two passes (dQ, then dK/dV), the single-pass kernel and the kernel
+    that runs both passes of a short sequence in one workgroup (each serves the shapes that fit it; the others fall back
+    to the two passes under any setting)."""
     L.check(L.lib().mmst_attn_bwd_config(request.param), "mmst_attn_bwd_config")
     assert L.lib().mmst_attn_bwd_mode() == request.param
     yield request.param
