@@ -67,34 +67,7 @@ __device__ __forceinline__ void stage(unsigned char* rm, unsigned char* tr, cons
   }
 }
 
-// The same staging in two halves, so that the global loads of the NEXT chunk can be in flight while the current
-// chunk is being consumed (the q-owner kernels; a decoder cross-attention launch has one workgroup per CU and
-// nothing else to hide that latency behind).
 constexpr int NTHR = 64 * 8;
-constexpr int SLOTS = KC * (GC / 8) / NTHR;
-struct Staged { uint4 v[SLOTS]; };
-__device__ __forceinline__ void stage_load(Staged& st, const bf16* src, int ld, int nvalid, int tid) {
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
-    const int c = tid + i * NTHR, row = c / (GC / 8), ch = c % (GC / 8);
-    st.v[i] = make_uint4(0, 0, 0, 0);
-    if (row < nvalid) st.v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-  }
-}
-template <bool RM, bool TR>
-__device__ __forceinline__ void stage_store(const Staged& st, unsigned char* rm, unsigned char* tr, int tid) {
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
-    const int c = tid + i * NTHR, row = c / (GC / 8), ch = c % (GC / 8);
-    if (RM) *reinterpret_cast<uint4*>(rm + rm_off(row, ch)) = st.v[i];
-    if (TR) {
-      const unsigned short* e = reinterpret_cast<const unsigned short*>(&st.v[i]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        *reinterpret_cast<unsigned short*>(tr + (ch * 8 + j) * TSTR + row * 2) = e[j];
-    }
-  }
-}
 
 // Row-major image of a streamed chunk by LDS-DMA (no registers, no LDS store instructions): 128 rows x 128 B, a wave
 // instruction fills 8 rows (1 KiB, contiguous in LDS); the chunk swizzle of rm_off() is applied on the global side (the
@@ -393,15 +366,12 @@ __device__ __forceinline__ BlockCoord locate(const AttnBatch& batch, int block) 
 // forward (BWD = false) and dQ pass (BWD = true): owner = queries
 // ------------------------------------------------------------------------------------------
 template <int HD, bool BWD> constexpr int q_smem_bytes() {
-  return Cfg<HD>::RM_BYTES * (BWD ? 2 : 1) + Cfg<HD>::TR_BYTES + KC * 4;
+  return 4 * Cfg<HD>::RM_BYTES + KC * 4;   // two stages of (K | V) row-major images, key bias
 }
 template <int HD, bool CAUSAL, bool BWD>
 __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, unsigned char* smem) {
   typedef Cfg<HD> C;
-  unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + C::RM_BYTES;                    // BWD only (row-major V)
-  unsigned char* Timg = smem + C::RM_BYTES * (BWD ? 2 : 1);    // fwd: V^T, bwd: K^T
-  float* bias = reinterpret_cast<float*>(Timg + C::TR_BYTES);
+  float* bias = reinterpret_cast<float*>(smem + 4 * C::RM_BYTES);
 
   const BlockCoord bc = locate<HD>(batch, block);
   const AttnProb& pr = batch.p[bc.g];
@@ -430,6 +400,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
   }
   if (TAILS && Tq_main == 0) return;   // uniform over the workgroup: nothing left for the tiled path
   const uint32_t rseed = attn_row_seed(pr.seed, (uint32_t)((b * H + hh) * Tq + (qvalid ? q : 0)));
+  const TrOff troff = tr_offsets<HD>(lane, hoff);
 
   bf16x8 qf[C::KS], dof[C::KS];
   load_owner<HD>(qf, pr.Q + (size_t)(b * Tq + (qvalid ? q : 0)) * pr.ldq + hh * HD, h, qvalid);
@@ -460,32 +431,35 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
   const int kvr = (!BWD && pr.kv_rows > 0) ? pr.kv_rows : Sk;
   const bf16* kbatch = pr.K + (size_t)b * kvr * pr.ldk + gcol;
   const bf16* vbatch = pr.V + (size_t)b * kvr * pr.ldv + gcol;
-  Staged kst, vst;
+  // The K and V chunks arrive by LDS-DMA (row-major images only; the transposed operand comes from transposing LDS
+  // reads) into one of two stages: the next chunk is in flight while this one is consumed.
+  // (`t` is the thread index: the call inside the chunk loop passes a copy the compiler cannot see through, so that
+  // its address arithmetic is redone there instead of being hoisted out of the loop into long-lived registers)
   float bst = -INFINITY;
-  auto fetch = [&](int c0) {
+  auto fetch = [&](int c0, int stg, int t) {
     const int nvalid = min(KC, Sk_main - c0);
-    stage_load(kst, kbatch + (size_t)c0 * pr.ldk, pr.ldk, nvalid, tid);
-    stage_load(vst, vbatch + (size_t)c0 * pr.ldv, pr.ldv, nvalid, tid);
+    stage_dma(smem + stg * 2 * C::RM_BYTES, kbatch + (size_t)c0 * pr.ldk, pr.ldk, nvalid, t);
+    stage_dma(smem + stg * 2 * C::RM_BYTES + C::RM_BYTES, vbatch + (size_t)c0 * pr.ldv, pr.ldv, nvalid, t);
     bst = -INFINITY;
-    if (tid < nvalid) bst = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + tid] * LOG2E : 0.f;
+    if (t < nvalid) bst = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + t] * LOG2E : 0.f;
   };
-  constexpr bool PREFETCH = !BWD;   // the staging registers would spill in the dQ pass
-  if (PREFETCH) fetch(0);
-  for (int c0 = 0; c0 < Sk_main; c0 += KC) {
+  if (Sk_main > 0) fetch(0, 0, tid);
+  int stg = 0;
+  for (int c0 = 0; c0 < Sk_main; c0 += KC, stg ^= 1) {
     const int nvalid = min(KC, Sk_main - c0);
-    if (!PREFETCH) fetch(c0);
-    __syncthreads();
-    if (!BWD) {
-      stage_store<true, false>(kst, Kimg, nullptr, tid);
-      stage_store<false, true>(vst, nullptr, Timg, tid);
-    } else {
-      stage_store<true, true>(kst, Kimg, Timg, tid);
-      stage_store<true, false>(vst, Vimg, nullptr, tid);
-    }
+    if (c0 > 0) __syncthreads();                  // every wave is done with the previous chunk's bias (and the other stage)
     if (tid < KC) bias[tid] = bst * inv_scale2;   // in score units: the accumulator of S starts from it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (PREFETCH && c0 + KC < Sk_main) fetch(c0 + KC);
+    if (c0 + KC < Sk_main) {
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));
+      fetch(c0 + KC, stg ^ 1, t2);
+    }
     if (!active) continue;
+    const unsigned char* Kimg = smem + stg * 2 * C::RM_BYTES;
+    const unsigned char* Vimg = Kimg + C::RM_BYTES;
+    const unsigned char* Timg = BWD ? Kimg : Vimg;   // transposed operand: K^T for dQ, V^T for the forward
     const int ntile = (nvalid + 31) >> 5;
     for (int t = 0; t < ntile; ++t) {
       const int lk0 = t * 32;
@@ -552,8 +526,8 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
         }
       }
       const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 0, lane, hoff), pf0, oacc, 0, 0, 0);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_tr<HD>(Timg, lk0, 1, lane, hoff), pf1, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_trd<HD>(Timg, lk0, troff, lane), pf0, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_trd<HD>(Timg, lk0 + 16, troff, lane), pf1, oacc, 0, 0, 0);
     }
   }
   if (!qvalid) return;
@@ -600,7 +574,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
 
 template <int HD, bool CAUSAL, bool BWD>
 __global__ void attn_q_kernel(const AttnBatch batch) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[q_smem_bytes<HD, BWD>()];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[q_smem_bytes<HD, BWD>()];
   attn_q_body<HD, CAUSAL, BWD>(batch, (int)blockIdx.x, smem);
 }
 
@@ -981,7 +955,7 @@ __global__ void attn_bwd_self_kernel(const AttnBatch batch) {
 template <int HD, bool CAUSAL>
 __global__ void attn_bwd_both_kernel(const AttnBatch batch, int nblocks) {
   constexpr int SM = kv_smem_bytes<HD>() > q_smem_bytes<HD, true>() ? kv_smem_bytes<HD>() : q_smem_bytes<HD, true>();
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
   if ((int)blockIdx.x < nblocks) attn_kv_body<HD, CAUSAL, true>(batch, (int)blockIdx.x, smem);
   else attn_q_body<HD, CAUSAL, true>(batch, (int)blockIdx.x - nblocks, smem);
 }

@@ -1,5 +1,6 @@
-"""Attention backward alone at the training shapes (64 molecules): tools/bench_attn.py [cross|modal] [p]
-Prints the time per launch of mmst_attn_bwd (whatever kernels it selects) measured with events."""
+"""Attention alone at the training shapes (64 molecules): tools/bench_attn.py [cross|modal] [p] [fwd]
+Prints the time per launch of mmst_attn_bwd (whatever kernels it selects), or of mmst_attn_fwd with a fourth
+argument, measured with events."""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -8,6 +9,8 @@ from multimodalspectraltransformer_amd import ops  # noqa: E402
 DEV = "cuda"
 which = sys.argv[1] if len(sys.argv) > 1 else "cross"
 p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+fwd = len(sys.argv) > 3
+launch = ops.attn_fwd_launch if fwd else ops.attn_bwd_launch
 B = 64
 shapes = [(4, 582, 32)] if which == "cross" else [(16, 129, 8)] * 3 + [(16, 66, 8)]
 hd = shapes[0][2]
@@ -31,13 +34,13 @@ for i, (H, S, _) in enumerate(shapes):
 batch = ops.attn_batch(groups, hd, False, p)
 ops.attn_fwd_launch(batch)
 for _ in range(3):
-    ops.attn_bwd_launch(batch)
+    launch(batch)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 N = 20
 e0.record()
 for _ in range(N):
-    ops.attn_bwd_launch(batch)
+    launch(batch)
 e1.record()
 torch.cuda.synchronize()
-print("%s p=%.2f: %.1f us per backward" % (which, p, e0.elapsed_time(e1) * 1000 / N))
+print("%s p=%.2f: %.1f us per %s" % (which, p, e0.elapsed_time(e1) * 1000 / N, "forward" if fwd else "backward"))
