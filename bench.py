@@ -84,6 +84,24 @@ def pmc_traffic(kernel):
     return None
 
 
+def pmc_traffic_token_step():
+    """HBM bytes per decode token step from the same summaries: a token step is one call of
+    mmst_decoder_stack_step, i.e. one launch of the decoder-stack kernel or, in its split form, one launch per layer
+    plus the token-batched feed-forward launches and a closing launch; the bytes of all of them are summed and divided
+    by the number of token steps of the counter run (the launches of the least-launched stack-kernel instance)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        ks = {k: v for k, v in d.items() if k.startswith("decode_stack_kernel") or k.startswith("decode_ffn_kernel")}
+        stack = [v["launches_in_pmc_run"] for k, v in ks.items() if k.startswith("decode_stack_kernel")]
+        if stack:
+            return sum(v["hbm_bytes_per_launch"] * v["launches_in_pmc_run"] for v in ks.values()) / min(stack)
+    return None
+
+
 def launch_ranks(n):
     """Start n ranks of this script (torch.distributed.run, one process per GPU) and pass their output through.
     Called before anything in this process has touched the GPU; the parent only waits."""
@@ -103,7 +121,8 @@ def decode_bench(args):
     """Secondary benchmark (BASELINE configuration 4): inference-only beam-search SMILES generation of
     validate_generate_MMT_v15_4.beam_search for `--batch` molecules x `--beams` beams x gen_len 64 positions on the
     config_V8 model (6 + 6 layers), encoder memory already resident.  One step = one whole search (replayed from a
-    hipGraph).  Roofline of its dominant kernel, the decoder-stack token step: algorithmic bytes (decoder weights
+    hipGraph).  Roofline of the decoder token step (one launch, or one launch per layer plus the token-batched
+    feed-forward launches, timed as a whole): algorithmic bytes (decoder weights
     once, every molecule's projected memory keys/values once, every sequence's cached prefix once, the new cache rows
     and logits written) over the launch durations measured with events on the launch stream."""
     from multimodalspectraltransformer_amd import synthetic as O
@@ -153,8 +172,9 @@ def decode_bench(args):
                       "global_batch": B, "parallelism": "dp1"},
            "tokens_per_s": B * W * gen_len * args.steps / dt,
            "roofline": {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
-                        "traffic": pmc_traffic("decode_stack_kernel"),
-                        "algorithmic_bytes_per_launch": sum(per_pos) / gen_len, "kernel": f"decode_stack_kernel<{W}>",
+                        "traffic": pmc_traffic_token_step(),
+                        "algorithmic_bytes_per_launch": sum(per_pos) / gen_len,
+                        "kernel": f"decoder token step (mmst_decoder_stack_step: decode_stack_kernel<{W}> per layer + decode_ffn_kernel)",
                         "launches": len(durs), "avg_us": 1e6 * sum(durs) / len(durs)}}
     print(json.dumps(res))
 
