@@ -145,6 +145,25 @@ __device__ __forceinline__ bf16x8 afrag_trd(const unsigned char* img, int row0, 
   if (HD == 8 && (lane & 31) >= 8) o = zero8();
   return o;
 }
+// Both operands of a 32-row tile (rows row0.. and row0 + 16..) issued as inline assembly, for loops that keep an LDS-DMA
+// in flight: the compiler puts s_waitcnt vmcnt(0) in front of every transposing read it can see while a DMA is pending
+// (which would make each wave wait for the NEXT chunk before it consumes this one); here the reads are waited for by
+// count.  No LDS store may sit between a barrier and a call of this.
+template <int HD>
+__device__ __forceinline__ void afrag_trd_pair(bf16x8& f0, bf16x8& f1, const unsigned char* img, int row0, const TrOff& off, int lane) {
+  const uint32_t base = (uint32_t)(uintptr_t)(LDS_AS const unsigned char*)(img + row0 * 128);
+  const uint32_t a0 = base + off.lo, a1 = base + off.hi;
+  s16x4 l0, h0, l1, h1;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l0) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0) : "v"(a1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(l1) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(h1) : "v"(a1));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  f0 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7));
+  f1 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+  if (HD == 8 && (lane & 31) >= 8) { f0 = zero8(); f1 = zero8(); }
+}
 // B operand of owner row `row` taken from a row-major image (what load_owner() reads from memory)
 template <int HD>
 __device__ __forceinline__ void owner_from_img(bf16x8 (&f)[Cfg<HD>::KS], const unsigned char* img, int row, int h, int hoff, bool valid) {
@@ -438,17 +457,19 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
   float bst = -INFINITY;
   auto fetch = [&](int c0, int stg, int t) {
     const int nvalid = min(KC, Sk_main - c0);
+    // the bias load goes first: it is waited for by count, and a wait for a load younger than the DMA would wait for
+    // the DMA as well
+    bst = -INFINITY;
+    if (t < nvalid) bst = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + t] : 0.f;
     stage_dma(smem + stg * 2 * C::RM_BYTES, kbatch + (size_t)c0 * pr.ldk, pr.ldk, nvalid, t);
     stage_dma(smem + stg * 2 * C::RM_BYTES + C::RM_BYTES, vbatch + (size_t)c0 * pr.ldv, pr.ldv, nvalid, t);
-    bst = -INFINITY;
-    if (t < nvalid) bst = pr.kbias ? pr.kbias[(size_t)b * Sk + c0 + t] * LOG2E : 0.f;
   };
   if (Sk_main > 0) fetch(0, 0, tid);
   int stg = 0;
   for (int c0 = 0; c0 < Sk_main; c0 += KC, stg ^= 1) {
     const int nvalid = min(KC, Sk_main - c0);
     if (c0 > 0) __syncthreads();                  // every wave is done with the previous chunk's bias (and the other stage)
-    if (tid < KC) bias[tid] = bst * inv_scale2;   // in score units: the accumulator of S starts from it
+    if (tid < KC) bias[tid] = bst * (LOG2E * inv_scale2);   // in score units: the accumulator of S starts from it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (c0 + KC < Sk_main) {
@@ -526,8 +547,10 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
         }
       }
       const bf16x8 pf0 = pack8(pv), pf1 = pack8(pv + 8);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_trd<HD>(Timg, lk0, troff, lane), pf0, oacc, 0, 0, 0);
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag_trd<HD>(Timg, lk0 + 16, troff, lane), pf1, oacc, 0, 0, 0);
+      bf16x8 tf0, tf1;
+      afrag_trd_pair<HD>(tf0, tf1, Timg, lk0, troff, lane);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf0, pf0, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf1, pf1, oacc, 0, 0, 0);
     }
   }
   if (!qvalid) return;
