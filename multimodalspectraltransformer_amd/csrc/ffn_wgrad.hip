@@ -204,14 +204,26 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
       const bf16x8 af = frag_join(lo, hi);
       if (i + PF < 16) issue_tile(i + PF, lo, hi);
       if (i == 8) {   // dh = g * mask(h): the A fragment of dW1 (lane <-> column j, k = the step's rows)
+        // The mask is read from the bf16 bit patterns two at a time (h >= 0: set where the magnitude bits are not
+        // zero), the pairs are converted together, and 1/(1-p) is applied once to the finished sums instead of to
+        // every element: 4.5 instead of 8 instructions per element of this block, a fifth of the loop.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT; ++jt) {
+          const u32x4 hw = __builtin_bit_cast(u32x4, hf[jt]);
+          float sel[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float gv = e < 4 ? g[jt][0][e] : g[jt][1][e - 4];
-            dh[jt][e] = (bf16)((float)hf[jt][e] > 0.f ? gv * dscale : 0.f);
-            b1p[jt] += (float)dh[jt][e];
+            const bool on = (hw[e >> 1] & ((e & 1) ? 0x7FFF0000u : 0x7FFFu)) != 0u;
+            sel[e] = on ? gv : 0.f;
+            b1p[jt] += sel[e];
           }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)sel[e];
+          dh[jt] = o;
+        }
       }
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt) {
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) stg[(jw + jt * 16 + 4 * q + e) * 129 + 16 * t + li] = aw1[jt][t][e];   // [j][k]
+        for (int e = 0; e < 4; ++e) stg[(jw + jt * 16 + 4 * q + e) * 129 + 16 * t + li] = aw1[jt][t][e] * dscale;   // [j][k]
     __syncthreads();
 #pragma unroll 4
     for (int r = 0; r < RW; ++r) {
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
     }
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
-      float v = b1p[jt];
+      float v = b1p[jt] * dscale;
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       if (q == 0) atomicAdd(pr.db1 + j0 + jw + jt * 16 + li, v);
