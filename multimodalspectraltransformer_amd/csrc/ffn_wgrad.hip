@@ -111,14 +111,20 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
     srow[jj] = (wave * JT + jj) * 4 + q;
     sch[jj] = (((li >> 1) ^ rsw(srow[jj])) << 1) | (li & 1);
   }
+  // The three base pointers as values: read through `pr` inside the loop they would be fetched from the kernel
+  // arguments again in every step (the waits of the loop are memory barriers to the compiler), a scalar load and a wait
+  // for it in front of each step's DMA.
+  const bf16* const gZ = pr.dZ;
+  const bf16* const gH = pr.H + j0;
+  const bf16* const gX = pr.X;
   auto stage = [&](int s, int b) {
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
       unsigned char* dst = smem + b * 3 * IMG + (wave * JT + jj) * 4 * 256;
       const size_t m = (size_t)(s * STEP + srow[jj]);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pr.dZ + m * DM + sch[jj] * 8), (lptr_t)(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pr.H + m * FF + j0 + sch[jj] * 8), (lptr_t)(dst + IMG), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pr.X + m * DM + sch[jj] * 8), (lptr_t)(dst + 2 * IMG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gZ + m * DM + sch[jj] * 8), (lptr_t)(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gH + m * FF + sch[jj] * 8), (lptr_t)(dst + IMG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gX + m * DM + sch[jj] * 8), (lptr_t)(dst + 2 * IMG), 16, 0, 0);
     }
   };
   // the ragged last step of the matrix goes through registers: rows past the end read as zero
