@@ -328,7 +328,7 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
     total += NJ * rs;
   }
   // 4 waves of 32 hidden columns (default) or 8 waves of 16 (setting 2 of mmst_ffn_wgrad_config).  Alone on the GPU the
-  // 8-wave shape is faster (120 against 137 us at 37248 rows); inside a training step its two 168-register waves per
+  // 8-wave shape was faster when both were measured (120 against 137 us at 37248 rows; the 4-wave shape has since gone to 127 us); inside a training step its two 168-register waves per
   // SIMD leave no room for the 240-register feed-forward backward of the other stream (8.30 against 7.95 ms per step).
   const int waves = ffn_wgrad_recompute() == 2 ? 8 : 4;
   GemmTap& tap = g_gemm_tap;
