@@ -336,13 +336,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-          bf16x8 h = frag_n<false>(himg, pw0 + mt * 16 + (lane & 15), tp, lane);
-          bf16x8 o;
+          // dh = (h > 0 ? g / (1 - p) : 0) on PAIRS of elements: the scaled pair is converted to two bf16 in one
+          // instruction and ANDed with a mask built from the saved activation's bit patterns (h >= 0, so a half is
+          // "on" when its magnitude bits are not zero: min(bits, 1) * 0xFFFF per half, packed 16-bit instructions):
+          // 3 instructions per element instead of 4.7 with a compare and a select per element.
+          const u32x4 hw = __builtin_bit_cast(u32x4, frag_n<false>(himg, pw0 + mt * 16 + (lane & 15), tp, lane));
+          u32x4 ow;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float gv = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
-            o[e] = (bf16)((float)h[e] > 0.f ? gv * dscale : 0.f);
+          for (int pr2 = 0; pr2 < 4; ++pr2) {
+            const int e = 2 * pr2;
+            const float g0 = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
+            const float g1 = e < 4 ? a1[mt][2 * tp][e + 1] : a1[mt][2 * tp + 1][e - 3];
+            const f32x2 gs = {g0 * dscale, g1 * dscale};
+            const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(gs, bf16x2));
+            // (as instructions: written with vector types the two packed operations come back as a compare and a
+            // select per half)
+            uint32_t on = hw[pr2] & 0x7FFF7FFFu;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(on), "s"(0x00010001u));
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(on) : "v"(on), "s"(0xFFFFFFFFu));
+            ow[pr2] = pk & on;
           }
+          const bf16x8 o = __builtin_bit_cast(bf16x8, ow);
           hf[mt][tp] = o;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), drsrc,
                                                  (int)(hoff[mt] + (uint32_t)(c * HC + tp * 32) * 2), 0, 0);
