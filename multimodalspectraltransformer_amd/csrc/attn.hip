@@ -238,6 +238,16 @@ template <int HD> __device__ __forceinline__ float row_delta(const AttnProb& pr,
   return s;
 }
 // dropout keep flag of (query-row seed, key): the same hash the tile code evaluates pairwise
+// attn_pair_bits() with the 24-bit multiply written as an instruction: where a lane hashes once per score (the key-owner
+// tiles) the compiler otherwise spends an AND per hash on clearing the upper bits the instruction ignores anyway
+__device__ __forceinline__ uint32_t attn_pair_bits_i(uint32_t row_seed, uint32_t pair_term) {
+  uint32_t t = row_seed + pair_term;
+  t ^= t >> 16;
+  asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(t) : "v"(t));
+  static_assert(ATTN_PAIR_K24 == 0x9E3779U, "constant of the instruction above");
+  t ^= t >> 16;
+  return t;
+}
 __device__ __forceinline__ bool keep_of(uint32_t row_seed, int key, uint32_t thr) {
   const uint32_t hb = attn_pair_bits(row_seed, (uint32_t)(key >> 1) * ATTN_PAIR_MUL);
   return ((hb >> ((key & 1) * 16)) & 0xFFFFu) >= thr;
@@ -708,7 +718,8 @@ __device__ __forceinline__ void attn_kv_body(const AttnBatch& batch, int block, 
           if (CAUSAL && key > qg) v = -INFINITY;
           const float p = __builtin_amdgcn_exp2f(v);
           // (no branch on `dropping` here: threshold 0 keeps everything, whatever the seed words hold)
-          const uint32_t hb = attn_pair_bits(rsv[j], pair_term);
+          // (head_dim 32: the instruction form costs that kernel registers it does not have)
+          const uint32_t hb = HD == 8 ? attn_pair_bits_i(rsv[j], pair_term) : attn_pair_bits(rsv[j], pair_term);
           const float pk = ((hb >> pair_shift) & 0xFFFFu) >= thr ? p : 0.f;
           pd[i] = pk;
           ds[i] = pk * dpacc[i] - p * dd[j];
@@ -867,7 +878,8 @@ __global__ void attn_bwd_self_kernel(const AttnBatch batch) {
         for (int j = 0; j < 4; ++j) {
           const int i = 4 * g4 + j;
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, bias2));
-          const uint32_t hb = attn_pair_bits(rsv[j], pair_term);
+          // (head_dim 32: the instruction form costs that kernel registers it does not have)
+          const uint32_t hb = HD == 8 ? attn_pair_bits_i(rsv[j], pair_term) : attn_pair_bits(rsv[j], pair_term);
           const float pk = ((hb >> pair_shift) & 0xFFFFu) >= thr ? p : 0.f;
           pd[i] = pk;
           ds[i] = pk * dpacc[i] - p * dd[j];
