@@ -221,18 +221,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   }
 #pragma unroll
   for (int j = 0; j < HD; ++j) offH[j] = src_offset<IMG_H_BWD>(pw0 + j * 8, lane, p0, M);
-  // image i of the sequence = phase (i % 3) of chunk (i / 3), into ring slot (i % 4)
+  // image i of the sequence = phase (i % 3) of chunk (i / 3), into ring slot (i % 4).  (The base pointers as values:
+  // read through `pr` they would be fetched from the kernel arguments again at every issue, the loop's waits being
+  // memory barriers to the compiler.)
+  const bf16* const gH = pr.H;
+  const bf16* const gW1 = pr.W1;
+  const bf16* const gW2 = pr.W2;
   auto issue = [&](int c, int ph, int i) {
     unsigned char* slot = smem + (i & (NSLOT - 1)) * RSLOT;
     if (ph == 1) {
 #pragma unroll
       for (int j = 0; j < HD; ++j)
-        glds16(pr.H + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>(), slot + (pw0 + j * 8) * 128);
+        glds16(gH + offH[j] + (uint32_t)c * chunk_stride<IMG_H_BWD>(), slot + (pw0 + j * 8) * 128);
     } else if (wdma) {
 #pragma unroll
       for (int j = 0; j < WD; ++j) {
-        const bf16* src = ph == 0 ? pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
-                                  : pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
+        const bf16* src = ph == 0 ? gW1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>()
+                                  : gW2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>();
         glds16(src, slot + (wave * WD + j) * 1024);
       }
     }
