@@ -461,17 +461,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
     offA[j] = src_offset<IMG_W1_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
     offB[j] = src_offset<IMG_W2_FWD>(wave * 8 * WD + j * 8, lane, p0, M);
   }
+  // (base pointers as values: read through `pr` they would be fetched from the kernel arguments again at every issue)
+  const bf16* const gW1 = pr.W1;
+  const bf16* const gW2 = pr.W2;
   auto issue_w1 = [&](int c) {
     unsigned char* dst = w1s + (c & 1) * SLOT + wave * WD * 1024;
     if (wdma)
 #pragma unroll
-      for (int j = 0; j < WD; ++j) glds16(pr.W1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
+      for (int j = 0; j < WD; ++j) glds16(gW1 + offA[j] + (uint32_t)c * chunk_stride<IMG_W1_FWD>(), dst + j * 1024);
   };
   auto issue_w2 = [&](int c) {
     unsigned char* dst = w2s + (c & 1) * SLOT + wave * WD * 1024;
     if (wdma)
 #pragma unroll
-      for (int j = 0; j < WD; ++j) glds16(pr.W2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
+      for (int j = 0; j < WD; ++j) glds16(gW2 + offB[j] + (uint32_t)c * chunk_stride<IMG_W2_FWD>(), dst + j * 1024);
   };
   // Everything the first step needs is requested before anything is waited for: the first linear1 image and, with a
   // prologue, the two 64-column halves of Wp as first-GEMM images in the (still unused) slots of the second weight.
