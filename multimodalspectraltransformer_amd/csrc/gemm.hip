@@ -110,12 +110,17 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
   };
 
   if (kbeg < kend) {
+    // (the problem's fields as values: read through `pr` inside the loop they are fetched from the kernel arguments
+    // again after every barrier, seven scalar loads and a wait for them per k step)
+    const bf16* const gP = pr.P;
+    const bf16* const gQ = pr.Q;
+    const int ldp = pr.ldp, ldq = pr.ldq, Pn = pr.Pn, Qn = pr.Qn, Kd = pr.K;
     uint4 rpA[NL], rqA[NL], rpB[NL], rqB[NL];
-    g2r<PT, NL>(rpA, pr.P, pr.ldp, p0, pr.Pn, kbeg * BK, pr.K, tid);
-    g2r<QT, NL>(rqA, pr.Q, pr.ldq, q0, pr.Qn, kbeg * BK, pr.K, tid);
+    g2r<PT, NL>(rpA, gP, ldp, p0, Pn, kbeg * BK, Kd, tid);
+    g2r<QT, NL>(rqA, gQ, ldq, q0, Qn, kbeg * BK, Kd, tid);
     if (kbeg + 1 < kend) {
-      g2r<PT, NL>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kbeg + 1) * BK, pr.K, tid);
-      g2r<QT, NL>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kbeg + 1) * BK, pr.K, tid);
+      g2r<PT, NL>(rpB, gP, ldp, p0, Pn, (kbeg + 1) * BK, Kd, tid);
+      g2r<QT, NL>(rqB, gQ, ldq, q0, Qn, (kbeg + 1) * BK, Kd, tid);
     }
     for (int kt = kbeg; kt < kend; kt += 2) {
       __syncthreads();
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
       r2s<QT, true, NL>(Qimg, rqA, tid);
       __syncthreads();
       if (kt + 2 < kend) {
-        g2r<PT, NL>(rpA, pr.P, pr.ldp, p0, pr.Pn, (kt + 2) * BK, pr.K, tid);
-        g2r<QT, NL>(rqA, pr.Q, pr.ldq, q0, pr.Qn, (kt + 2) * BK, pr.K, tid);
+        g2r<PT, NL>(rpA, gP, ldp, p0, Pn, (kt + 2) * BK, Kd, tid);
+        g2r<QT, NL>(rqA, gQ, ldq, q0, Qn, (kt + 2) * BK, Kd, tid);
       }
       compute_tile();
       if (kt + 1 < kend) {
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
         r2s<QT, true, NL>(Qimg, rqB, tid);
         __syncthreads();
         if (kt + 3 < kend) {
-          g2r<PT, NL>(rpB, pr.P, pr.ldp, p0, pr.Pn, (kt + 3) * BK, pr.K, tid);
-          g2r<QT, NL>(rqB, pr.Q, pr.ldq, q0, pr.Qn, (kt + 3) * BK, pr.K, tid);
+          g2r<PT, NL>(rpB, gP, ldp, p0, Pn, (kt + 3) * BK, Kd, tid);
+          g2r<QT, NL>(rqB, gQ, ldq, q0, Qn, (kt + 3) * BK, Kd, tid);
         }
         compute_tile();
       }
@@ -300,6 +305,10 @@ __global__ __launch_bounds__(512, NS * KB <= 128 ? 2 : 1) void wgrad_dma_kernel(
     const int c16 = lane & 15;
     rcol[j] = (((c16 >> 1) ^ fsw(rrow[j])) << 4) + ((c16 & 1) << 3);   // logical column (elements) of this LDS slot
   }
+  // (base pointers and strides as values: read through `pr` they are fetched from the kernel arguments at every issue)
+  const bf16* const gP = pr.P;
+  const bf16* const gQ = pr.Q;
+  const int ldp = pr.ldp, ldq = pr.ldq;
   auto issue = [&](int step) {
     const int k0 = (kbeg + step) * KB;
     unsigned char* st = smem + (step % NS) * STAGE;
@@ -307,9 +316,9 @@ __global__ __launch_bounds__(512, NS * KB <= 128 ? 2 : 1) void wgrad_dma_kernel(
     for (int j = 0; j < NJ; ++j) {
       int row = k0 + rrow[j];
       row = row < K ? row : K - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(pr.P + (size_t)row * pr.ldp + p0 + rcol[j]),
+      __builtin_amdgcn_global_load_lds((gptr_t)(gP + (size_t)row * ldp + p0 + rcol[j]),
                                        (lptr_t)(st + (wave * NJ + j) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pr.Q + (size_t)row * pr.ldq + q0 + rcol[j]),
+      __builtin_amdgcn_global_load_lds((gptr_t)(gQ + (size_t)row * ldq + q0 + rcol[j]),
                                        (lptr_t)(st + IMG + (wave * NJ + j) * 1024), 16, 0, 0);
     }
   };
