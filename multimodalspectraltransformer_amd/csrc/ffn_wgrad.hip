@@ -29,6 +29,8 @@ constexpr int DM = 128, FF = 2048, JC = 128, NJ = FF / JC, RS = 16, STEP = 32;
 // of LDS keep the other stream's 64 KiB launches off the CU: slower in a step); three buffers for h and two for the L2-
 // resident dz / x tiles (56 KiB, room for two attention workgroups beside: 145 us alone against 135, 7.56 against 7.50 ms
 // per step: what the kernels beside this one lack is registers, not LDS).
+// (Four operand tiles in flight instead of two inside a step, the extra two requested once g is computed: 9 spilled
+// registers in the loop, 190 us instead of 133.)
 constexpr int NBUF = 3;
 constexpr int IMG = STEP * 256;   // one 32-row x 128-column bf16 tile, rows of 256 B
 
