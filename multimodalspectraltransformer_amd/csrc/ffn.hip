@@ -319,13 +319,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
         const uint32_t mw = mk[mt][0] << (8 * (c & 1));   // the flags of an odd chunk sit 8 bits below those of an even one
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-          bf16x8 o;
+          // on pairs: the two flags of a pair sit 16 bits apart (sign_bit()), so shifted to bits 15 / 31 an arithmetic
+          // shift of each 16-bit half by 15 spreads them into the mask word of the pair's two bf16 values
+          u32x4 ow;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float gv = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
-            o[e] = (bf16)((mw & (1u << sign_bit(0, tp, e))) ? gv * dscale : 0.f);
+          for (int pr2 = 0; pr2 < 4; ++pr2) {
+            const int e = 2 * pr2;
+            const float g0 = e < 4 ? a1[mt][2 * tp][e] : a1[mt][2 * tp + 1][e - 4];
+            const float g1 = e < 4 ? a1[mt][2 * tp][e + 1] : a1[mt][2 * tp + 1][e - 3];
+            const f32x2 gs = {g0 * dscale, g1 * dscale};
+            const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(gs, bf16x2));
+            static_assert(sign_bit(0, 0, 1) - sign_bit(0, 0, 0) == 16, "flags of a pair 16 bits apart");
+            uint32_t on = mw << (15 - sign_bit(0, tp, e));
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(on) : "v"(on));   // (the constant's low half for both shifts)
+            ow[pr2] = pk & on;
           }
-          hf[mt][tp] = o;
+          hf[mt][tp] = __builtin_bit_cast(bf16x8, ow);
         }
         if (c & 1) {
 #pragma unroll
