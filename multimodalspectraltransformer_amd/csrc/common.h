@@ -90,6 +90,21 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
+// Sum over the 16 lanes of a row (the lanes with equal lane >> 4), left in every one of them.  Data-parallel-primitive
+// operands (neighbour exchange inside the add instruction) instead of __shfl_xor, which goes through the LDS crossbar
+// (ds_bpermute_b32) with an address register and a wait per step: quads by two permutes, then the mirrored half row
+// (lane i with 7 - i: the other quad's sum) and the mirrored row (i with 15 - i: the other half's sum).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -329,11 +329,8 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[MT][8], const GemmProb& p
     for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float a = pg[tp][e], b = pb[tp][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        pg[tp][e] = a;
-        pb[tp][e] = b;
+        pg[tp][e] = row16_sum(pg[tp][e]);
+        pb[tp][e] = row16_sum(pb[tp][e]);
       }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][128]
