@@ -105,13 +105,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return v;
+}
+// over 8 consecutive lanes (lanes with equal lane >> 3)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  return v;
+}
+// whole wave: the rows by data-parallel-primitive operands, the four rows through the LDS crossbar
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
   return v;
 }

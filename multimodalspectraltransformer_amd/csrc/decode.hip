@@ -126,9 +126,7 @@ __device__ __forceinline__ void gemv_k128(const bf16* __restrict__ W, const floa
       for (int u = 0; u < U; ++u) {
         const int n = (p0 + u) * RP + r0;
         float s = dot8b(a[u], va, 0.f) + dot8b(b[u], vb, 0.f);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
+        s = row8_sum(s);
         if (sub == 0 && n < rows) emit(r, n, s + (bias ? bias[n] : 0.f));
       }
     }
