@@ -287,28 +287,30 @@ __device__ __forceinline__ void layernorm_rows(Smem<R>& sm, float z, const float
   lds_barrier();
 }
 
-// merge of the per-lane online-softmax states (m, l, acc[8]) of Q query rows at once: the 4 key slots of a wave (lanes
-// with equal head), then the waves through LDS (two barriers for all the rows); results -> out + r*D (bf16-rounded)
+// merge of the per-lane online-softmax states (m, l, acc[8]) of Q query rows at once: the 4 key slots of a wave (the
+// lanes of a quad), then the waves through LDS (two barriers for all the rows); results -> out + r*D (bf16-rounded)
 template <int R, int Q>
 __device__ __forceinline__ void merge_softmax_all(Smem<R>& sm, float (&m)[Q], float (&l)[Q], float (&acc)[Q][HD], bf16* out,
                                                   int tid) {
   static_assert(Q <= R, "one partial array per sequence of the workgroup");
-  const int lane = tid & 63, wave = tid >> 6, hh = lane & 15;
+  // lane = 4 head + key slot: the four key slots of a head are the lanes of a quad, merged by quad permutes inside the
+  // add / max instructions (no trip through the LDS crossbar)
+  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 2;
 #pragma unroll
   for (int r = 0; r < Q; ++r) {
-    float M = fmaxf(m[r], __shfl_xor(m[r], 16));
-    M = fmaxf(M, __shfl_xor(M, 32));
+    float M = fmaxf(m[r], dpp_f32<0xB1>(m[r]));
+    M = fmaxf(M, dpp_f32<0x4E>(M));
     const float f = __builtin_amdgcn_exp2f(m[r] - M);
     float lr = l[r] * f;
-    lr += __shfl_xor(lr, 16);
-    lr += __shfl_xor(lr, 32);
+    lr += dpp_f32<0xB1>(lr);
+    lr += dpp_f32<0x4E>(lr);
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
       acc[r][d] *= f;
-      acc[r][d] += __shfl_xor(acc[r][d], 16);
-      acc[r][d] += __shfl_xor(acc[r][d], 32);
+      acc[r][d] += dpp_f32<0xB1>(acc[r][d]);
+      acc[r][d] += dpp_f32<0x4E>(acc[r][d]);
     }
-    if (lane < NH) {
+    if ((lane & 3) == 0) {
       sm.part[r][wave][hh][0] = M;
       sm.part[r][wave][hh][1] = lr;
 #pragma unroll
@@ -336,7 +338,7 @@ __device__ __forceinline__ void merge_softmax_all(Smem<R>& sm, float (&m)[Q], fl
 // Attention of Q query rows (q + r*qstride, 16 heads x 8) over the SAME `nkeys` keys: K row of key j at kbase + j*ld, V
 // at vbase + j*ld (bf16, 128 wide) -- unless `slot_of` is given: then key j lives in the cache of sequence slot_of[j] of
 // the molecule, kbase + (slot_of[j]*cap + j)*ld (a beam's history points into the caches of the beams it descends
-// from).  Lane = (key slot, head): 16 lanes read one key's 256-byte row, a wave covers 4 keys per step, the
+// from).  Lane = 4 head + key slot: a wave covers 4 keys per step (each key's 256-byte row read by 16 of its lanes), the
 // workgroup 64.  If last_k != nullptr (Q == 1 only), key nkeys-1 is read from LDS instead (the row this workgroup
 // has just produced).  Results -> out + r*D (bf16-rounded).
 // STREAM: the keys/values are read once per launch by this workgroup only (the projected encoder memory): they are
@@ -348,7 +350,7 @@ __device__ __forceinline__ void attend_scores(const float* q, int qstride, const
                                               const int32_t* slot_of, int cap, int tid, float (&m)[Q], float (&l)[Q],
                                               float (&acc)[Q][HD]) {
   const int lane = tid & 63, wave = tid >> 6;
-  const int hh = lane & 15, slot = wave * 4 + (lane >> 4);
+  const int hh = lane >> 2, slot = wave * 4 + (lane & 3);
   const float scale2 = rsqrtf((float)HD) * LOG2E;
   bf16x2 qv[Q][4];
 #pragma unroll
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
       if (R > 1 && pos + 1 <= 4 * NWAVE) {
         // at most one key per lane: the key/value rows of ALL R sequences are requested before the first one is used
         // (one round trip to the caches instead of R), the arithmetic is that of the general loop for a single key
-        const int lane = tid & 63, hh = lane & 15, key = (tid >> 6) * 4 + (lane >> 4);
+        const int lane = tid & 63, hh = lane >> 2, key = (tid >> 6) * 4 + (lane & 3);
         const bool valid = key <= pos;
         const float scale2 = rsqrtf((float)HD) * LOG2E;
         bf16x8 kt[R], vt[R];
