@@ -297,13 +297,21 @@ __device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& 
     }
     const float M = wave_max(m);
     const float f = __builtin_amdgcn_exp2f(m - M);
-    l = wave_sum(l * f);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) acc[d] = wave_sum(acc[d] * f);
-    if (lane == 0) {
-      store_row8(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, acc, l > 0.f ? 1.0f / l : 0.f);
-      pr.lse[stat] = M + __builtin_amdgcn_logf(l);
+    float red = 0.f;   // lane 8 of a row keeps l, lanes 0..7 the output elements: one trip through the crossbar
+    {
+      const float a = row16_sum(l * f);
+      red = (lane & 15) == 8 ? a : red;
     }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float a = row16_sum(acc[d] * f);
+      red = (lane & 15) == d ? a : red;
+    }
+    red += __shfl_xor(red, 16);
+    red += __shfl_xor(red, 32);
+    l = __shfl(red, 8);
+    if (lane < 8) pr.O[(size_t)(b * Tq + q) * pr.ldo + hh * HD + lane] = (bf16)(red * (l > 0.f ? 1.0f / l : 0.f));
+    if (lane == 0) pr.lse[stat] = M + __builtin_amdgcn_logf(l);
   } else {
     const bf16x8 dorow = ldrow8(pr.dO + (size_t)(b * Tq + q) * pr.lddo + hh * HD);
     const float delta = dot8(dorow, ldrow8(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD));
@@ -318,12 +326,16 @@ __device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& 
 #pragma unroll
       for (int d = 0; d < 8; ++d) acc[d] += ds * (float)kt[d];
     }
+    float red = 0.f;   // as in kv_owner_tail(): one trip through the crossbar for the eight sums
 #pragma unroll
-    for (int d = 0; d < 8; ++d) acc[d] = wave_sum(acc[d]);
-    if (lane == 0) {
-      store_row8(pr.dQ + (size_t)(b * Tq + q) * pr.lddq + hh * HD, acc, 1.0f);
-      pr.delta[stat] = delta;
+    for (int d = 0; d < 8; ++d) {
+      const float a = row16_sum(acc[d]);
+      red = (lane & 15) == d ? a : red;
     }
+    red += __shfl_xor(red, 16);
+    red += __shfl_xor(red, 32);
+    if (lane < 8) pr.dQ[(size_t)(b * Tq + q) * pr.lddq + hh * HD + lane] = (bf16)red;
+    if (lane == 0) pr.delta[stat] = delta;
   }
 }
 
@@ -357,15 +369,19 @@ __device__ __forceinline__ void kv_owner_tail(const AttnProb& pr, const TailCtx&
       dk[d] += ds * (float)qrow[d];
     }
   }
+  // sixteen wave-wide sums: inside the rows of 16 lanes each by itself, then lane i of every row keeps sum i and the
+  // four rows are added through the LDS crossbar ONCE (2 exchanges instead of 32); lanes 0..15 store one element each
+  float red = 0.f;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
-    dk[d] = wave_sum(dk[d]);
-    dv[d] = wave_sum(dv[d]);
+    const float a = row16_sum(dk[d]), c = row16_sum(dv[d]);
+    red = (lane & 15) == d ? a : red;
+    red = (lane & 15) == 8 + d ? c : red;
   }
-  if (lane == 0) {
-    store_row8(pr.dK + (size_t)(b * Sk + key) * pr.lddk + hh * HD, dk, 1.0f);
-    store_row8(pr.dV + (size_t)(b * Sk + key) * pr.lddv + hh * HD, dv, 1.0f);
-  }
+  red += __shfl_xor(red, 16);
+  red += __shfl_xor(red, 32);
+  if (lane < 8) pr.dK[(size_t)(b * Sk + key) * pr.lddk + hh * HD + lane] = (bf16)red;
+  else if (lane < 16) pr.dV[(size_t)(b * Sk + key) * pr.lddv + hh * HD + lane - 8] = (bf16)red;
 }
 
 struct BlockCoord { int g, b, hg, blk; };   // hg = head-group index
