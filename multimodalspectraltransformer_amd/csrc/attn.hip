@@ -307,9 +307,8 @@ __device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& 
       const float a = row16_sum(acc[d] * f);
       red = (lane & 15) == d ? a : red;
     }
-    red += __shfl_xor(red, 16);
-    red += __shfl_xor(red, 32);
-    l = __shfl(red, 8);
+    red = xor32_sum(xor16_sum(red));
+    l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, red), 8));
     if (lane < 8) pr.O[(size_t)(b * Tq + q) * pr.ldo + hh * HD + lane] = (bf16)(red * (l > 0.f ? 1.0f / l : 0.f));
     if (lane == 0) pr.lse[stat] = M + __builtin_amdgcn_logf(l);
   } else {
@@ -332,8 +331,7 @@ __device__ __forceinline__ void q_owner_tail(const AttnProb& pr, const TailCtx& 
       const float a = row16_sum(acc[d]);
       red = (lane & 15) == d ? a : red;
     }
-    red += __shfl_xor(red, 16);
-    red += __shfl_xor(red, 32);
+    red = xor32_sum(xor16_sum(red));
     if (lane < 8) pr.dQ[(size_t)(b * Tq + q) * pr.lddq + hh * HD + lane] = (bf16)red;
     if (lane == 0) pr.delta[stat] = delta;
   }
@@ -378,8 +376,7 @@ __device__ __forceinline__ void kv_owner_tail(const AttnProb& pr, const TailCtx&
     red = (lane & 15) == d ? a : red;
     red = (lane & 15) == 8 + d ? c : red;
   }
-  red += __shfl_xor(red, 16);
-  red += __shfl_xor(red, 32);
+  red = xor32_sum(xor16_sum(red));
   if (lane < 8) pr.dK[(size_t)(b * Sk + key) * pr.lddk + hh * HD + lane] = (bf16)red;
   else if (lane < 16) pr.dV[(size_t)(b * Sk + key) * pr.lddv + hh * HD + lane - 8] = (bf16)red;
 }
@@ -458,7 +455,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
     for (int s = 0; s < C::KS; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
-    delta += __shfl_xor(delta, 32);
+    delta = xor32_sum(delta);
     if (qvalid) {
       lse2 = pr.lse[(size_t)(b * H + hh) * Tq + q];
       if (h == 0) pr.delta[(size_t)(b * H + hh) * Tq + q] = delta;
@@ -535,7 +532,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
         float tmax = sv[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sv[i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale2;
+        tmax = xor32_max(tmax) * scale2;
         const float mn = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
@@ -612,7 +609,7 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
     }
   }
   if (!BWD) {
-    l += __shfl_xor(l, 32);
+    l = xor32_sum(l);
     const float inv = l > 0.f ? dscale / l : 0.f;
     store_rows<HD>(pr.O + (size_t)(b * Tq + q) * pr.ldo + hh * HD, oacc, inv, h);
     if (h == 0) pr.lse[(size_t)(b * H + hh) * Tq + q] = m + __builtin_amdgcn_logf(l);

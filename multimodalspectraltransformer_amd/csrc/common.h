@@ -119,16 +119,21 @@ __device__ __forceinline__ float row8_sum(float v) {
   v += dpp_f32<0x141>(v);
   return v;
 }
-// whole wave: the rows by data-parallel-primitive operands, the four rows through the LDS crossbar
-__device__ __forceinline__ float wave_sum(float v) {
-  v = row16_sum(v);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+// Exchanges between the rows of 16 lanes, in the vector ALU as well (the lane-swap instructions of gfx950): both
+// operands start as v; v_permlane32_swap exchanges the upper half of the first with the lower half of the second, which
+// leaves (lower, lower) and (upper, upper); v_permlane16_swap does the same with the odd rows of the first and the even
+// rows of the second.  (Two wait states between a vector write of an operand and the swap.)
+__device__ __forceinline__ void lanes_swap32(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float wave_max(float v) {
-  v = row16_max(v);
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
+__device__ __forceinline__ void lanes_swap16(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// v + (v of lane ^ 32), v + (v of lane ^ 16), and the maxima
+__device__ __forceinline__ float xor32_sum(float v) { float a = v, b = v; lanes_swap32(a, b); return a + b; }
+__device__ __forceinline__ float xor16_sum(float v) { float a = v, b = v; lanes_swap16(a, b); return a + b; }
+__device__ __forceinline__ float xor32_max(float v) { float a = v, b = v; lanes_swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_max(float v) { float a = v, b = v; lanes_swap16(a, b); return fmaxf(a, b); }
+// whole wave, no trip through the LDS crossbar
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }

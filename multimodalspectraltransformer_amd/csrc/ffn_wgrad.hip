@@ -303,8 +303,7 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
       float v = b1p[jt] * dscale;
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
+      v = xor32_sum(xor16_sum(v));
       if (q == 0) atomicAdd(pr.db1 + j0 + jw + jt * 16 + li, v);
     }
     if (do_b2) atomicAdd(pr.db2 + tid, b2p);

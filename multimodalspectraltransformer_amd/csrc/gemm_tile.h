@@ -207,16 +207,14 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][8], const GemmProb& pr, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += z[tp][e];
     }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = xor32_sum(xor16_sum(s));
     const float mean = s * (1.0f / 128.0f);
     float vs = 0.f;
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { float d = z[tp][e] - mean; vs += d * d; }
-    vs += __shfl_xor(vs, 16);
-    vs += __shfl_xor(vs, 32);
+    vs = xor32_sum(xor16_sum(vs));
     const float rstd = rsqrtf(vs * (1.0f / 128.0f) + 1e-5f);
     if (ok) {
 #pragma unroll
@@ -302,10 +300,8 @@ __device__ __forceinline__ void epi_lnbwd(f32x4 (&acc)[MT][8], const GemmProb& p
         pb[tp][e] += dy[e];
       }
     }
-    s1 += __shfl_xor(s1, 16);
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 16);
-    s2 += __shfl_xor(s2, 32);
+    s1 = xor32_sum(xor16_sum(s1));
+    s2 = xor32_sum(xor16_sum(s2));
     s1 *= (1.0f / 128.0f);
     s2 *= (1.0f / 128.0f);
     if (ok) {
