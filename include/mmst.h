@@ -123,6 +123,11 @@ typedef struct {
   const void* w_1; const float* b_1; const void* w_2; const float* b_2;
   const float* g1; const float* be1; const float* g2; const float* be2; const float* g3; const float* be3;
   const void* w_1t; const void* w_2t;   /* bf16 transposes of linear1 / linear2, backward pass only */
+  /* Optional fragment-major images (mmst_fragment_bf16) of the six weight matrices, f_cqkv of all 384 rows, and of their
+   * transposes (ft_cqkv: of the first 128 rows, the query projection): with all of f_* present mmst_decoder_stack_fwd may
+   * take its two-launches-per-layer form, with all of ft_* the backward entry points theirs; NULL = never. */
+  const void* f_qkv; const void* f_o; const void* f_cqkv; const void* f_co; const void* f_1; const void* f_2;
+  const void* ft_qkv; const void* ft_o; const void* ft_cqkv; const void* ft_co; const void* ft_1; const void* ft_2;
 } mmst_dec_params;
 
 typedef struct {
@@ -258,6 +263,13 @@ typedef struct {
  * (models_MMT_v15_4.py:1244, validate_generate_MMT_v15_4.py:751). */
 int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int nhead, float drop_p, uint32_t seed,
                            void* stream);
+/* nl decoder layers in sequence (layer l + 1 reads what layer l wrote; p[l] / a[l] / seeds[l] as for
+ * mmst_decoder_layer_fwd): the loop over self.layers of nn.TransformerDecoder behind :963.  Same saved activations and
+ * dropout masks as nl calls of mmst_decoder_layer_fwd; for target sequences of at most 64 positions under the causal
+ * mask a layer takes two launches instead of eight (a workgroup per molecule keeps the molecule's rows in LDS).
+ * wstream (optional, may be NULL): a second stream for the K|V projections of the memory, joined into stream. */
+int mmst_decoder_stack_fwd(int nl, const mmst_dec_params* const* p, const mmst_dec_acts* const* a, int nhead, float drop_p,
+                           const uint32_t* seeds, void* stream, void* wstream);
 int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
                            const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, void* stream);
 int mmst_decoder_layer_bwd_data(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,
@@ -356,6 +368,16 @@ int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, 
  * weights the backward pass reads in step with the bf16 weight copy after an optimizer step. */
 int mmst_transpose_bf16(const void* src, void* dst, int n, const uint32_t* offsets, int rows, int cols, void* stream);
 
+/* Fragment-major image of a bf16 matrix A[rows][cols] (rows a multiple of 16, cols of 32) for kernels that take their
+ * v_mfma_f32_16x16x32_bf16 weight operand straight from memory: tile (i, j) = rows 16 i .., columns 32 j .. is stored as
+ * 64 lanes x 8 elements, lane (r = lane & 15, g = lane >> 4) = A[16 i + r][32 j + 8 g .. + 7], tiles in row-major order,
+ * so that one wave instruction reads one contiguous KiB.  transpose == 0: A = src (row stride ld); otherwise A is the
+ * transpose of src, A[i][k] = src[k * ld + i].  Keeps the images the decoder kernels read in step with the bf16 weight
+ * copy after an optimizer step (no counterpart in the reference: a layout copy like mmst_transpose_bf16). */
+typedef struct { const void* src; void* dst; int rows, cols, ld, transpose; } mmst_frag_desc;
+#define MMST_FRAG_MAX 32   /* descriptors per launch; longer lists take several launches */
+int mmst_fragment_bf16(int n, const mmst_frag_desc* descs, void* stream);
+
 /* ---- CLIP contrastive head on the encoder half (utils_MMT/models_CLIP_v15_4.py), all fp32 ---- */
 
 /* C[M][N] = alpha * sum_k A(i,k) B(k,j) + beta * C + bias[j], with A(i,k) = A[i*sai + k*sak] and
@@ -397,6 +419,7 @@ int mmst_seq_mean_bwd(const float* dmean, void* dmem, int B, int L, void* stream
 #define MMST_MAX_LAYERS 8
 #define MMST_MAX_RANGES 16
 #define MMST_MAX_FFN 128
+#define MMST_MAX_FRAG 96
 enum { MMST_SEG_DECODER = 0, MMST_SEG_CROSS = 1, MMST_SEG_EMBED = 2, MMST_SEG_MODAL0 = 16 /* + encoder depth */ };
 
 typedef struct {
@@ -430,6 +453,8 @@ typedef struct {
   float* P; float* G; float* M; float* V; void* Pb; void* PbT;
   int n_ranges; long range_lo[MMST_MAX_RANGES]; long range_hi[MMST_MAX_RANGES];
   int n_ffn; uint32_t ffn1_off[MMST_MAX_FFN]; uint32_t ffn2_off[MMST_MAX_FFN];   /* linear1 / linear2 offsets in Pb */
+  /* fragment-major weight images to refresh after the optimizer (the f_* / ft_* of dec_p), or n_frag = 0 */
+  int n_frag; mmst_frag_desc frag[MMST_MAX_FRAG];
 } mmst_step_plan;
 
 typedef struct {

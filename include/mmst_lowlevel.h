@@ -148,6 +148,12 @@ int mmst_ffn_wgrad_mode(void);   /* the setting in force: 0, 1, 2 or 3 */
  * stream's kernels); negative: back to the default.  All forms give the same results to bf16 rounding. */
 int mmst_attn_bwd_config(int mode);
 int mmst_attn_bwd_mode(void);    /* the setting in force: 0..15 */
+/* mmst_decoder_stack_fwd and the decoder part of mmst_train_step on target sequences of at most 64 positions: 1 (default)
+ * = a workgroup per molecule runs everything of a layer but the cross-attention in two launches per layer; 0 = the
+ * launch sequences of the per-layer entry points; negative: back to the default.  Same saved activations and dropout
+ * masks either way; results agree to bf16 rounding. */
+int mmst_decoder_fused_config(int on);
+int mmst_decoder_fused_mode(void);
 
 /* ---- diagnostic: HIP events around every launch of ONE GEMM variant, recorded on the launch stream.
  * mmst_tap_config allocates host memory and events (the only entry point of the library that does). ---- */

@@ -144,8 +144,11 @@ _DEC_P = ("w_qkv", "b_qkv", "w_o", "b_o", "w_cqkv", "b_cqkv", "w_co", "b_co", "w
           "g1", "be1", "g2", "be2", "g3", "be3")
 
 
+_DEC_W = ("qkv", "o", "cqkv", "co", "1", "2")
+
+
 class DecParams(C.Structure):
-    _fields_ = _ptrs(*(_DEC_P + ("w_1t", "w_2t")))
+    _fields_ = _ptrs(*(_DEC_P + ("w_1t", "w_2t") + tuple("f_" + w for w in _DEC_W) + tuple("ft_" + w for w in _DEC_W)))
 
 
 class DecGrads(C.Structure):
@@ -198,7 +201,12 @@ class EmbedShared(C.Structure):
 # ---------------------------------------------------------------------------------------------
 # whole training step (mmst_train_step)
 # ---------------------------------------------------------------------------------------------
-MAX_LAYERS, MAX_RANGES, MAX_FFN = 8, 16, 128
+MAX_LAYERS, MAX_RANGES, MAX_FFN, MAX_FRAG = 8, 16, 128, 96
+
+
+class FragDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                ("transpose", C.c_int)]
 SEG_DECODER, SEG_CROSS, SEG_EMBED, SEG_MODAL0 = 0, 1, 2, 16
 
 
@@ -218,7 +226,8 @@ class StepPlan(C.Structure):
                       "d_pe_trg", "fc_out_w", "fc_out_b", "d_fc_out_w", "d_fc_out_b", "logits", "dlogits", "loss",
                       "dmem", "dmem_in", "dtrg", "P", "G", "M", "V", "Pb", "PbT") +
                 [("n_ranges", C.c_int), ("range_lo", C.c_long * MAX_RANGES), ("range_hi", C.c_long * MAX_RANGES),
-                 ("n_ffn", C.c_int), ("ffn1_off", C.c_uint32 * MAX_FFN), ("ffn2_off", C.c_uint32 * MAX_FFN)])
+                 ("n_ffn", C.c_int), ("ffn1_off", C.c_uint32 * MAX_FFN), ("ffn2_off", C.c_uint32 * MAX_FFN),
+                 ("n_frag", C.c_int), ("frag", FragDesc * MAX_FRAG)])
 
 
 SEGMENT_CALLBACK = C.CFUNCTYPE(None, C.c_int, C.c_void_p)

@@ -3,6 +3,7 @@
 // projection and their gradients).  Structs are plain C (see gemm.h / attn.h).
 #include "../../include/mmst_lowlevel.h"
 #include "attn.h"
+#include "dec_fused.h"
 #include "ffn.h"
 #include "gemm.h"
 #include <stddef.h>
@@ -89,6 +90,14 @@ int mmst_attn_bwd_config(int mode) {
   return MMST_OK;
 }
 int mmst_attn_bwd_mode(void) { return attn_bwd_merged(); }
+
+// decoder layers of short target sequences with a workgroup per molecule (mmst_decoder_stack_fwd and the decoder part of
+// mmst_train_step): 1 = on, 0 = the per-layer launch sequences, negative = the default (on, or MMST_DEC_FUSED)
+int mmst_decoder_fused_config(int on) {
+  dec_fused_set(on);
+  return MMST_OK;
+}
+int mmst_decoder_fused_mode(void) { return dec_fused_enabled() ? 1 : 0; }
 
 // ---- diagnostic tap: times every launch of one GEMM variant with HIP events on its own stream ----
 int mmst_tap_config(int epi, int p_contraction_major, int q_contraction_major, int capacity) {

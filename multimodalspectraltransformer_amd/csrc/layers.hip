@@ -2,6 +2,7 @@
 // attention launches (see gemm.h / attn.h).  Nothing is allocated and no state is kept here.
 #include "../../include/mmst.h"
 #include "attn.h"
+#include "dec_fused.h"
 #include "ffn.h"
 #include "gemm.h"
 #include <mutex>
@@ -551,6 +552,67 @@ int mmst_decoder_layer_fwd(const mmst_dec_params* p, const mmst_dec_acts* a, int
                            seed + 4, seed + 5);
     fb.p[0].ws = a->ffn_ws;
     RUN(launch_ffn_fwd(fb, st));
+  }
+  return MMST_OK;
+}
+
+// ---- nl decoder layers in sequence (layer l + 1 reads what layer l wrote) ----
+// Short target sequences (T <= 64, causal): two launches per layer instead of eight.  The K|V projections of the
+// memory for all layers are one grouped launch (on wstream when given: it runs beside the first self-attention block);
+// per layer the cross-attention launch is followed by ONE launch that finishes the layer (out_proj + norm2, feed-forward
+// block + norm3) and starts the next one (QKV, causal self-attention, out_proj + norm1, cross-attention queries) with a
+// workgroup per molecule (dec_fused.hip).  Otherwise: nl calls of mmst_decoder_layer_fwd.
+int mmst_decoder_stack_fwd(int nl, const mmst_dec_params* const* p, const mmst_dec_acts* const* a, int nhead, float drop_p,
+                           const uint32_t* seeds, void* stream_, void* wstream_) {
+  if (nl < 1 || nl > MMST_MAX_LAYERS || !p || !a || !seeds || nhead != 16) return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
+  if (wst == st) wst = nullptr;
+  bool fused = dec_fused_enabled();
+  for (int l = 0; l < nl; ++l) {
+    if (!p[l] || !a[l]) return MMST_ERR_ARG;
+    if (a[l]->T < 1 || a[l]->T > 64 || a[l]->no_causal || a[l]->B != a[0]->B || a[l]->T != a[0]->T || a[l]->L != a[0]->L)
+      fused = false;
+    if (l > 0 && a[l]->x != a[l - 1]->y) fused = false;
+    if (!a[l]->ffn_ws) fused = false;   // [8][B*T][128] fp32: the fused path keeps four partial sums there
+    if (!p[l]->f_qkv || !p[l]->f_o || !p[l]->f_cqkv || !p[l]->f_co || !p[l]->f_1 || !p[l]->f_2) fused = false;
+  }
+  if (!fused) {
+    for (int l = 0; l < nl; ++l) RUN(mmst_decoder_layer_fwd(p[l], a[l], nhead, drop_p, seeds[l], stream_));
+    return MMST_OK;
+  }
+  const int B = a[0]->B, T = a[0]->T, L = a[0]->L, ML = B * L;
+  GemmBatch gb;
+  gb.n = 0;
+  for (int l = 0; l < nl; ++l)
+    if (!a[l]->kv_ready)
+      gb.p[gb.n++] = fwd_linear(a[l]->mem, ML, D, (const bf16*)p[l]->w_cqkv + D * D, 2 * D, p[l]->b_cqkv + D, a[l]->kvc);
+  if (gb.n > 0) {
+    if (wst) RUN(mmst_stream_fork(st, wst));   // the memory exists
+    RUN(launch_gemm(gb, EPI_BIAS, false, false, wst ? wst : st));
+  }
+  DecFusedFwd f;
+  memset(&f, 0, sizeof(f));
+  f.B = B; f.T = T; f.drop_p = drop_p;
+  f.do_head = 1; f.ph = *p[0]; f.ah = *a[0]; f.seed_h = seeds[0];
+  RUN(launch_dec_fused_fwd(f, st));
+  if (gb.n > 0 && wst) RUN(mmst_stream_fork(wst, st));
+  for (int l = 0; l < nl; ++l) {
+    AttnBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.n = 1; ab.hd = D / nhead; ab.causal = 0; ab.drop_p = drop_p;
+    AttnProb& q = ab.p[0];
+    const bf16* kv = (const bf16*)a[l]->kvc;
+    q.Q = (const bf16*)a[l]->qc; q.ldq = D;
+    q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
+    q.kbias = a[l]->mem_bias;
+    q.O = (bf16*)a[l]->attn2; q.ldo = D; q.lse = a[l]->lse2;
+    q.B = B; q.H = nhead; q.Tq = T; q.Sk = L; q.seed = seeds[l] + 2;
+    RUN(launch_attn_fwd(ab, st));
+    memset(&f, 0, sizeof(f));
+    f.B = B; f.T = T; f.drop_p = drop_p;
+    f.do_tail = 1; f.pt = *p[l]; f.at = *a[l]; f.seed_t = seeds[l]; f.ws = a[l]->ffn_ws;
+    if (l + 1 < nl) { f.do_head = 1; f.ph = *p[l + 1]; f.ah = *a[l + 1]; f.seed_h = seeds[l + 1]; }
+    RUN(launch_dec_fused_fwd(f, st));
   }
   return MMST_OK;
 }

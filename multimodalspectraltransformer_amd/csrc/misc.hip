@@ -608,6 +608,55 @@ int mmst_cast_bf16(const float* src, void* dst, int rows, int cols, int ld_out, 
   return MMST_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct FragArgs { int n; mmst_frag_desc d[MMST_FRAG_MAX]; };
+// one thread per 16-byte piece of the image: piece p of matrix y = lane p % 64 of tile p / 64 (tiles in row-major order,
+// 16 rows x 32 columns each); lane (r = lane & 15, g = lane >> 4) holds A[16 i + r][32 j + 8 g .. + 7]
+__global__ __launch_bounds__(256) void fragment_kernel(const FragArgs A) {
+  const mmst_frag_desc& d = A.d[blockIdx.y];
+  const int pieces = d.rows * d.cols / 8, kt = d.cols / 32;
+  const bf16* src = (const bf16*)d.src;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < pieces; p += gridDim.x * 256) {
+    const int lane = p & 63, tile = p >> 6, j = tile % kt, i = tile / kt;
+    const int row = 16 * i + (lane & 15), col = 32 * j + 8 * (lane >> 4);
+    bf16x8 v;
+    if (!d.transpose) {
+      v = *reinterpret_cast<const bf16x8*>(src + (size_t)row * d.ld + col);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[(size_t)(col + e) * d.ld + row];
+    }
+    *reinterpret_cast<bf16x8*>((bf16*)d.dst + (size_t)p * 8) = v;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mmst_fragment_bf16(int n, const mmst_frag_desc* descs, void* stream) {
+  if (n < 0 || (n > 0 && !descs)) return MMST_ERR_ARG;
+  for (int base = 0; base < n; base += MMST_FRAG_MAX) {
+    FragArgs A;
+    A.n = n - base < MMST_FRAG_MAX ? n - base : MMST_FRAG_MAX;
+    int most = 0;
+    for (int i = 0; i < A.n; ++i) {
+      const mmst_frag_desc& d = descs[base + i];
+      if (!d.src || !d.dst || d.rows < 16 || (d.rows & 15) || d.cols < 32 || (d.cols & 31) || d.ld < 1) return MMST_ERR_ARG;
+      if (!d.transpose && (d.ld & 7)) return MMST_ERR_ARG;
+      A.d[i] = d;
+      const int pieces = d.rows * d.cols / 8;
+      if (pieces > most) most = pieces;
+    }
+    int gx = (most + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(fragment_kernel, dim3(gx, A.n), dim3(256), 0, (hipStream_t)stream, A);
+    MMST_CHECK_LAUNCH();
+  }
+  return MMST_OK;
+}
+
 int mmst_transpose_bf16(const void* src, void* dst, int n, const uint32_t* offsets, int rows, int cols, void* stream) {
   if (!src || !dst || !offsets || n < 1 || n > TRANSPOSE_MAX || rows < 1 || cols < 1) return MMST_ERR_ARG;
   TransposeArgs A;

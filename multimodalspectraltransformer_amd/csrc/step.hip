@@ -40,7 +40,7 @@ bool plan_ok(const mmst_step_plan* pl) {
   if (pl->n_enc_layers < 1 || pl->n_enc_layers > MMST_MAX_LAYERS || pl->n_dec_layers < 1 || pl->n_dec_layers > MMST_MAX_LAYERS)
     return false;
   if (pl->vocab < 1 || pl->vocab > VPAD || pl->n_ranges < 0 || pl->n_ranges > MMST_MAX_RANGES || pl->n_ffn < 0 ||
-      pl->n_ffn > MMST_MAX_FFN || pl->ir_group >= pl->n_groups)
+      pl->n_ffn > MMST_MAX_FFN || pl->ir_group >= pl->n_groups || pl->n_frag < 0 || pl->n_frag > MMST_MAX_FRAG)
     return false;
   for (int l = 0; l < pl->n_enc_layers; ++l)
     if (!pl->modal_p[l] || !pl->modal_g[l] || !pl->modal_a[l] || !pl->modal_w[l] || !pl->cross_p[l] || !pl->cross_g[l] ||
@@ -63,7 +63,7 @@ bool plan_ok(const mmst_step_plan* pl) {
 }
 
 int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed_group* eg, const mmst_embed_shared* es,
-            hipStream_t st) {
+            hipStream_t st, hipStream_t wst) {
   const int B = pl->B, T = pl->T, L = pl->L, n = pl->n_groups;
   const int nl = pl->n_enc_layers, ndl = pl->n_dec_layers;
   RUN(mmst_embed_fwd(n, eg, es, st));
@@ -92,10 +92,18 @@ int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed
   // decoder on the batch-first token matrix: input token of (t, b) = trg[b][t]
   RUN(launch_trg_embed_fwd(ar->trg, 1, ar->trg_ld, pl->embed_trg, pl->pe_trg, pl->trg_emb, B, T, ar->drop_embed,
                            layer_seed(ar->step_seed, UID_TRG), st, pl->loss));
-  for (int l = 0; l < ndl; ++l) {
-    mmst_dec_acts a = *pl->dec_a[l];
-    a.T = T; a.kv_ready = 0; a.no_causal = 0;
-    RUN(mmst_decoder_layer_fwd(pl->dec_p[l], &a, 16, ar->drop_layers, layer_seed(ar->step_seed, UID_DEC + l), st));
+  // the decoder reads the fragment-major weight images, which the previous step's optimizer refreshed on wst
+  if (pl->n_frag > 0) RUN(mmst_stream_fork(wst, st));
+  {
+    mmst_dec_acts acts[MMST_MAX_LAYERS];
+    const mmst_dec_acts* ap[MMST_MAX_LAYERS];
+    for (int l = 0; l < ndl; ++l) {
+      acts[l] = *pl->dec_a[l];
+      acts[l].T = T; acts[l].kv_ready = 0; acts[l].no_causal = 0;
+      ap[l] = &acts[l];
+      seeds[l] = layer_seed(ar->step_seed, UID_DEC + l);
+    }
+    RUN(mmst_decoder_stack_fwd(ndl, pl->dec_p, ap, 16, ar->drop_layers, seeds, st, wst));
   }
   {
     GemmProb q = zero_prob();
@@ -220,6 +228,7 @@ int optimizer(const mmst_step_plan* pl, const mmst_step_args* ar, hipStream_t st
     RUN(mmst_transpose_bf16(pl->Pb, pl->PbT, pl->n_ffn, pl->ffn1_off, MMST_FF, D, wst));
     RUN(mmst_transpose_bf16(pl->Pb, pl->PbT, pl->n_ffn, pl->ffn2_off, D, MMST_FF, wst));
   }
+  if (pl->n_frag > 0) RUN(mmst_fragment_bf16(pl->n_frag, pl->frag, wst));
   return MMST_OK;
 }
 
@@ -254,7 +263,7 @@ int mmst_train_step(const mmst_step_plan* pl, const mmst_step_args* ar, void* st
       if (hipMemsetAsync(pl->G + pl->range_lo[i], 0, sizeof(float) * (size_t)(pl->range_hi[i] - pl->range_lo[i]), st) !=
           hipSuccess)
         return MMST_ERR_LAUNCH;
-  RUN(forward(pl, ar, eg, &es, st));
+  RUN(forward(pl, ar, eg, &es, st, wst));
   RUN(backward(pl, ar, eg, &es, st, wst));
   if (ar->adam_step > 0) RUN(optimizer(pl, ar, st, wst));
   return MMST_OK;

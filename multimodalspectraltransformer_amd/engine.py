@@ -90,6 +90,21 @@ class Arena:
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
         # transposed bf16 copies of the feed-forward weights (same offsets as in Pb), read by the backward pass
         self.PbT = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        # fragment-major images of the decoder's weight matrices and of their transposes (same offsets as in Pb): the
+        # decoder kernels that keep a molecule's rows in LDS read their weight operands from these
+        self.PbF = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.PbTF = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.frag_descs = []
+        for l in range(ndl):
+            pre = f"decoder.layers.{l}."
+            for name, rows, cols, trows in (("self_attn.in_proj_weight", 3 * D, D, 3 * D), ("self_attn.out_proj.weight", D, D, D),
+                                            ("multihead_attn.in_proj_weight", 3 * D, D, D),
+                                            ("multihead_attn.out_proj.weight", D, D, D),
+                                            ("linear1.weight", FF, D, FF), ("linear2.weight", D, FF, D)):
+                o = 2 * self.offset[pre + name]
+                self.frag_descs.append((self.Pb.data_ptr() + o, self.PbF.data_ptr() + o, rows, cols, cols, 0))
+                # the image of the transpose of the first `trows` rows: [cols][trows]
+                self.frag_descs.append((self.Pb.data_ptr() + o, self.PbTF.data_ptr() + o, cols, trows, cols, 1))
         self.ffn1_offsets = [self.offset[k] for k in order if k.endswith("linear1.weight")]
         self.ffn2_offsets = [self.offset[k] for k in order if k.endswith("linear2.weight")]
         self.M = None
@@ -125,6 +140,23 @@ class Arena:
     def pbt(self, k):
         return self.PbT.data_ptr() + 2 * self.offset[k]
 
+    def pbf(self, k):
+        return self.PbF.data_ptr() + 2 * self.offset[k]
+
+    def pbtf(self, k):
+        return self.PbTF.data_ptr() + 2 * self.offset[k]
+
+    def frag_array(self):
+        arr = (L.FragDesc * max(len(self.frag_descs), 1))()
+        for i, (src, dst, rows, cols, ld, tr) in enumerate(self.frag_descs):
+            arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].ld, arr[i].transpose = src, dst, rows, cols, ld, tr
+        return arr
+
+    def refresh_fragments(self):
+        """PbF / PbTF <- fragment-major images of the decoder weights in Pb."""
+        if self.frag_descs:
+            L.check(L.lib().mmst_fragment_bf16(len(self.frag_descs), self.frag_array(), L.stream_ptr()), "mmst_fragment_bf16")
+
     def refresh_transposed(self):
         """PbT <- transposes of the linear1 / linear2 weights in Pb (one launch per shape, 128 matrices each)."""
         for offs, rows, cols in ((self.ffn1_offsets, FF, D), (self.ffn2_offsets, D, FF)):
@@ -142,6 +174,7 @@ class Arena:
         L.check(L.lib().mmst_cast_bf16(C.c_void_p(self.P.data_ptr()), C.c_void_p(self.Pb.data_ptr()), 1,
                                        self.total, self.total, L.stream_ptr()), "mmst_cast_bf16")
         self.refresh_transposed()
+        self.refresh_fragments()
         self.shadow_stale = False
         self.weights_serial += 1
 
@@ -383,6 +416,11 @@ class Plan:
             setattr(g, f, ar.g32(key))
         p.w_1t = ar.pbt(prefix + "linear1.weight")
         p.w_2t = ar.pbt(prefix + "linear2.weight")
+        for f, k in (("qkv", "self_attn.in_proj_weight"), ("o", "self_attn.out_proj.weight"),
+                     ("cqkv", "multihead_attn.in_proj_weight"), ("co", "multihead_attn.out_proj.weight"),
+                     ("1", "linear1.weight"), ("2", "linear2.weight")):
+            setattr(p, "f_" + f, ar.pbf(prefix + k))
+            setattr(p, "ft_" + f, ar.pbtf(prefix + k))
         return p, g
 
     def _build_structs(self):
@@ -652,9 +690,11 @@ class Engine:
                                            C.c_void_p(ar.p32("pe_trg.weight")), C.c_void_p(_P(pl.trg_emb)), B, T,
                                            C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)), st),
                     "mmst_trg_embed_fwd")
-        for l in range(m.num_decoder_layers):
-            L.check(lib.mmst_decoder_layer_fwd(C.byref(pl.dec_p[l]), C.byref(pl.dec_a[l]), 16, C.c_float(p_drop),
-                                               C.c_uint32(self.layer_seed(64 + l)), st), "mmst_decoder_layer_fwd")
+        ndl = m.num_decoder_layers
+        pp = (C.c_void_p * ndl)(*[C.addressof(pl.dec_p[l]) for l in range(ndl)])
+        aa = (C.c_void_p * ndl)(*[C.addressof(pl.dec_a[l]) for l in range(ndl)])
+        seeds = (C.c_uint32 * ndl)(*[self.layer_seed(64 + l) for l in range(ndl)])
+        L.check(lib.mmst_decoder_stack_fwd(ndl, pp, aa, 16, C.c_float(p_drop), seeds, st, None), "mmst_decoder_stack_fwd")
         out = pl.dec_acts[m.num_decoder_layers - 1]["y"]
         ops.gemm([dict(P=_P(out), Q=ar.pb("fc_out.weight"), C=_P(pl.logits), bias=ar.p32("fc_out.bias"),
                        ldp=D, ldq=D, ldc=VPAD, Pn=B * T, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
@@ -776,6 +816,11 @@ class Engine:
         sp.n_ffn = len(ar.ffn1_offsets)
         for i, (o1, o2) in enumerate(zip(ar.ffn1_offsets, ar.ffn2_offsets)):
             sp.ffn1_off[i], sp.ffn2_off[i] = o1, o2
+        if len(ar.frag_descs) > L.MAX_FRAG:
+            raise L.MMSTError("too many fragment-major weight images for mmst_step_plan")
+        sp.n_frag = len(ar.frag_descs)
+        for i, d in enumerate(ar.frag_array()[:sp.n_frag]):
+            sp.frag[i] = d
         pl._step_plan = sp
         pl._step_args = L.StepArgs()
         return sp

@@ -125,6 +125,7 @@ class FusedAdamW:
                                        C.c_void_p(ar.Pb.data_ptr() + 2 * lo), C.c_long(hi - lo), C.c_float(self.lr),
                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                        C.c_float(self.wd), self.step_count, C.c_float(grad_scale), st), "mmst_adamw")
+        ar.refresh_fragments()   # read by the decoder's forward pass: on this stream
         # the transposed feed-forward weights are read by the backward pass only: refresh them on the engine's second
         # stream, beside the next forward pass; Engine.backward waits for ar.transposed_ready
         main = torch.cuda.current_stream()
