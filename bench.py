@@ -117,7 +117,7 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def decode_bench(args):
+def decode_bench(args, quiet=False):
     """Secondary benchmark (BASELINE configuration 4): inference-only beam-search SMILES generation of
     validate_generate_MMT_v15_4.beam_search for `--batch` molecules x `--beams` beams x gen_len 64 positions on the
     config_V8 model (6 + 6 layers), encoder memory already resident.  One step = one whole search (replayed from a
@@ -176,7 +176,41 @@ def decode_bench(args):
                         "algorithmic_bytes_per_launch": sum(per_pos) / gen_len,
                         "kernel": f"decoder token step (mmst_decoder_stack_step: decode_stack_kernel<{W}> per layer + decode_ffn_kernel)",
                         "launches": len(durs), "avg_us": 1e6 * sum(durs) / len(durs)}}
-    print(json.dumps(res))
+    if not quiet:
+        print(json.dumps(res))
+    return res
+
+
+def secondary_metrics(args, tm, batches, steps=5):
+    """The two secondary metrics, measured after the primary timed region on the same GPU (a few seconds):
+    gen_step: the training step with the reference's default in-training generation (config_V8.json gen_SMI_sequence
+    true, sampling_method "mix": models_MMT_v15_4.py:1070, :1222-1297), `steps` steps after one warm-up step;
+    decode: BASELINE configuration 4, beam search for 256 molecules x 3 beams x 64 positions (`--decode`), `steps`
+    searches after two warm-up searches."""
+    out = {}
+    cfg = tm.config
+    old = (cfg.gen_SMI_sequence, cfg.sampling_method)
+    cfg.gen_SMI_sequence, cfg.sampling_method = True, "mix"
+    try:
+        tm.training_step(batches[0], 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tm.training_step(batches[i % len(batches)], i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["gen_step"] = {"ms_per_step": 1000 * dt / steps, "molecules_per_s": steps * args.batch / dt, "steps": steps,
+                           "workload": f"training step as above plus in-training generation, gen_SMI_sequence=True, "
+                                       f"sampling_method='mix', {cfg.max_len - 1} positions, {args.batch} molecules"}
+    finally:
+        cfg.gen_SMI_sequence, cfg.sampling_method = old
+    del tm
+    torch.cuda.empty_cache()
+    dargs = argparse.Namespace(batch=256, beams=3, steps=steps, warmup=2)
+    d = decode_bench(dargs, quiet=True)
+    out["decode"] = {"ms_per_search": d["ms_per_step"], "molecules_per_s": d["value"], "tokens_per_s": d["tokens_per_s"],
+                     "steps": steps, "workload": d["config"]["workload"], "roofline": d["roofline"]}
+    return out
 
 
 def main():
@@ -190,11 +224,15 @@ def main():
     ap.add_argument("--gen", action="store_true", help="also run the in-training greedy generation (secondary metric)")
     ap.add_argument("--decode", action="store_true", help="secondary benchmark: beam-search decode instead of training")
     ap.add_argument("--beams", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary metrics (training step with in-training generation; beam-search decode)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed blocks of --steps steps (the first one is `value`)")
     args = ap.parse_args()
     if args.decode:
         if args.batch == 64 and "--batch" not in sys.argv:
             args.batch = 256
-        return decode_bench(args)
+        decode_bench(args)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -262,23 +300,51 @@ def main():
         L.check(lib.mmst_tap_config(100 if recompute else L.EPI_ATOMIC, 1, 1, 256 * args.steps), "mmst_tap_config")
     gaps = os.environ.get("MMST_BENCH_GAPS") == "1"   # diagnostic: GPU idle time between consecutive steps
     evs = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if gaps:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = tm.training_step(batches[i % len(batches)], i)
-        if gaps:
-            e1.record()
-            evs.append((e0, e1))
-    t_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (the GPU may still be running)
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    red_wait, red_coll, red_bytes = [], [], []
+
+    def timed_block(first):
+        """--steps training steps between two barrier + synchronize pairs; seconds (max over ranks), host enqueue time"""
+        nonlocal out
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if gaps and first:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = tm.training_step(batches[i % len(batches)], i)
+            if gaps and first:
+                e1.record()
+                evs.append((e0, e1))
+            if world > 1 and first:
+                red_coll.append(tm.reducer.collectives)
+                red_bytes.append(tm.reducer.bytes_reduced)
+                red_wait.append((tm.reducer.wait_events, tm.reducer.wait_host_s))
+        t_enq = time.perf_counter() - t0   # host time to enqueue the steps (the GPU may still be running)
+        sync()
+        dt_ = time.perf_counter() - t0
+        t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t), t_enq
+
+    out = None
+    dt, t_enqueue = timed_block(True)
+    repeats = [dt]
+    for _ in range(max(args.repeats, 1) - 1):
+        repeats.append(timed_block(False)[0])
     loss = float(out["loss"])
+    # the tap's average covers the timed steps only: read it before the isolated steps below
+    tap_read = None
+    if tap:
+        ms = C.c_float(0)
+        cnt = C.c_int(0)
+        flop = C.c_double(0)
+        byts = C.c_double(0)
+        name = C.create_string_buffer(128)
+        lib.mmst_tap_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        lib.mmst_tap_read(C.byref(ms), C.byref(cnt), C.byref(flop), C.byref(byts), name, 128)
+        tap_read = (ms.value, cnt.value, flop.value, byts.value, name.value.decode())
+        L.check(lib.mmst_tap_config(-1, 0, 0, 0), "mmst_tap_config")
     # host cost of enqueueing ONE step with an empty GPU queue (in the timed loop above the host runs ahead of the GPU
     # until the hardware queue is full and then waits for it, so the loop's enqueue time only mirrors the GPU time)
     iso = []
@@ -289,7 +355,8 @@ def main():
         iso.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     host_isolated_ms = 1000 * sorted(iso)[len(iso) // 2]
-    if rehearsal and world > 1:
+    replicas_identical = None
+    if world > 1:
         # replicas that average their gradients every step stay bit-identical
         ar = tm.model._engine.arena
         mine = {k: float(ar.P[ar.offset[k]: ar.offset[k] + ar.numel[k]].double().sum()) for k in ar.order}
@@ -297,6 +364,7 @@ def main():
         dist.all_gather_object(sums, mine)
         bad = [k for k in ar.order if any(s[k] != sums[0][k] for s in sums)]
         assert not bad, f"replicas diverged in {len(bad)} of {len(ar.order)} tensors, e.g. {bad[:6]}"
+        replicas_identical = True
 
     if rank == 0:
         mols = world * args.batch * args.steps
@@ -312,18 +380,28 @@ def main():
                                       f"gen_SMI_sequence={bool(args.gen)}",
                           "global_batch": world * args.batch, "parallelism": f"dp{world}"},
                "final_loss": loss,
-               "model_tflops": mols * FLOP_PER_MOL_STEP / dt / 1e12}
+               "model_tflops": mols * FLOP_PER_MOL_STEP / dt / 1e12,
+               # the same timed block again (--repeats in all, the first one above): one noisy box does not decide
+               "ms_per_step_repeats": [1000 * r / args.steps for r in repeats],
+               "ms_per_step_min": 1000 * min(repeats) / args.steps,
+               "ms_per_step_median": 1000 * sorted(repeats)[len(repeats) // 2] / args.steps}
+        if world > 1:
+            # gradient exchange of rank 0 in the first timed block: what backward did not hide is the time finish()
+            # held the compute stream up
+            waits = [(w[0][0].elapsed_time(w[0][1]) if w[0] is not None else 0.0) + 1000.0 * w[1] for w in red_wait]
+            res["allreduce_wait_ms_per_step"] = sum(waits) / max(len(waits), 1)
+            res["collectives_per_step"] = sum(red_coll) / max(len(red_coll), 1)
+            res["bytes_reduced_per_step"] = sum(red_bytes) / max(len(red_bytes), 1)
+            res["replicas_identical"] = replicas_identical
         if gaps:
             res["gpu_idle_between_steps_ms"] = sum(evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(len(evs) - 1)) / (len(evs) - 1)
             res["gpu_ms_inside_step"] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-        if tap:
-            ms = C.c_float(0)
-            cnt = C.c_int(0)
-            flop = C.c_double(0)
-            byts = C.c_double(0)
-            name = C.create_string_buffer(128)
-            lib.mmst_tap_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
-            lib.mmst_tap_read(C.byref(ms), C.byref(cnt), C.byref(flop), C.byref(byts), name, 128)
+        if tap_read is not None:
+            class _V:   # (the tap was read right after the timed blocks)
+                def __init__(self, v):
+                    self.value = v
+            ms, cnt, flop, byts = (_V(v) for v in tap_read[:4])
+            name = _V(tap_read[4].encode())
             if cnt.value > 0:
                 avg_s = ms.value / 1000.0 / cnt.value
                 # the roof that binds: the larger of bytes / HBM peak and flops / MFMA peak per launch
@@ -344,6 +422,8 @@ def main():
                                        "algorithmic_bytes_per_launch": byts.value / cnt.value,
                                        "hbm_frac": byts.value / cnt.value / avg_s / 8.0e12,
                                        "kernel": name.value.decode(), "launches": cnt.value, "avg_us": avg_s * 1e6}
+        if world == 1 and not args.no_secondary:
+            res["secondary"] = secondary_metrics(args, tm, batches)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

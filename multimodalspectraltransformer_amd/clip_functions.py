@@ -171,30 +171,48 @@ class CLIPMultiGPU:
         if self.reducer is None or self.reducer.flat is not ar.G:
             self.reducer = GradReducer(ar.G, ar.reduce_segments(), self.world,
                                        active=clip_active_ranges(ar, self.config.training_mode))
+        # Small gradients outside the segments of the flat buffer travel packed, asynchronously: the two projection
+        # heads and fp1 are final before the encoder backward starts, so their all-reduce is issued at its first
+        # segment callback and runs beside it; what the caller's SMILES model receives follows after its backward.
+        pending = []
+
+        def reduce_packed(tensors):
+            tensors = [t for t in tensors if t is not None]
+            if not tensors:
+                return
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            if flat.is_cuda and dist.get_backend() == "gloo":   # several ranks on one card (rehearsal): through the host
+                host = flat.cpu()
+                dist.all_reduce(host)
+                flat.copy_(host)
+                pending.append((None, flat, tensors))
+            else:
+                pending.append((dist.all_reduce(flat, async_op=True), flat, tensors))
+
+        head_params = [q for m in (clip.CB_projection, clip.MT_projection) for q in m.parameters()]
+        head_ids = {id(q) for q in head_params}
         on_segment = None
         if self.world > 1:
             def on_segment(name):
-                if name != "decoder":   # nothing on the decoder side has a gradient; fp1 is sent with the heads below
+                if name == "decoder":   # nothing on the decoder side has a gradient: the first callback of the backward
+                    reduce_packed([ar.grad_view("fp1.weight"), ar.grad_view("fp1.bias")] + [q.grad for q in head_params])
+                else:
                     self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),))
         loss, losses, dfeat = clip.loss_and_backward(batch, feats.detach(), on_segment=on_segment)
         if feats.requires_grad:
             feats.backward(dfeat)      # the caller's SMILES model: gradient of the mean loss at its output
         scale = 1.0
         if self.world > 1:
+            reduce_packed([q.grad for g in self.optimizer.torch_opt.param_groups for q in g["params"]
+                           if id(q) not in head_ids])
             scale = self.reducer.finish()
-            small = [ar.grad_view("fp1.weight"), ar.grad_view("fp1.bias")]
-            small += [p.grad for g in self.optimizer.torch_opt.param_groups for p in g["params"] if p.grad is not None]
-            flat = torch.cat([t.reshape(-1) for t in small])
-            if flat.is_cuda and dist.get_backend() == "gloo":
-                host = flat.cpu()
-                dist.all_reduce(host)
-                flat.copy_(host)
-            else:
-                dist.all_reduce(flat)
-            off = 0
-            for t in small:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
+            for work, flat, tensors in pending:
+                if work is not None:
+                    work.wait()
+                off = 0
+                for t in tensors:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
         self.optimizer.step(grad_scale=scale)
         self.global_step += 1
         self.last_train_loss = loss.clone()

@@ -128,14 +128,14 @@ __device__ __forceinline__ void proj_to_scratch(const f32x4 (&acc)[1][4], float*
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int t = mt * 16 + r;
-    f32x4 v = acc[0][mt] + bv;
-    if (dp > 0.f) {
+    f32x4 v = (acc[0][mt] + bv) * dscale;
+    {   // no branch on the dropout probability: without dropout the threshold is 0 and every comparison keeps
       const uint32_t idx = (uint32_t)(m0 + t) * 128u + (uint32_t)n;
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
         const uint32_t h = drop_bits(seed, (idx + e) >> 1);
-        v[e] = ((h & 0xFFFFu) >= thr) ? v[e] * dscale : 0.f;
-        v[e + 1] = ((h >> 16) >= thr) ? v[e + 1] * dscale : 0.f;
+        v[e] = ((h & 0xFFFFu) >= thr) ? v[e] : 0.f;
+        v[e + 1] = ((h >> 16) >= thr) ? v[e + 1] : 0.f;
       }
     }
     *reinterpret_cast<f32x4*>(Zf + t * ZS + n) = v;
@@ -237,13 +237,11 @@ __device__ __forceinline__ void ffn_chunk(f32x4 (&acc2)[1][4], const bf16x8 (&w1
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc1[nt][mt][e], dscale, bv[e]), 0.f);
-      if (dp > 0.f) {
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const uint32_t hb = attn_pair_bits(rseed[mt], (uint32_t)((col + e) >> 1) * ATTN_PAIR_MUL);
-          v[e] = ((hb & 0xFFFFu) >= thr) ? v[e] : 0.f;
-          v[e + 1] = ((hb >> 16) >= thr) ? v[e + 1] : 0.f;
-        }
+      for (int e = 0; e < 4; e += 2) {
+        const uint32_t hb = attn_pair_bits(rseed[mt], (uint32_t)((col + e) >> 1) * ATTN_PAIR_MUL);
+        v[e] = ((hb & 0xFFFFu) >= thr) ? v[e] : 0.f;
+        v[e + 1] = ((hb >> 16) >= thr) ? v[e + 1] : 0.f;
       }
       *reinterpret_cast<uint2*>(Hc + (mt * 16 + r) * HS + lc * 2) = pack4(v);
     }
@@ -301,9 +299,11 @@ __global__ __launch_bounds__(NTHR) void dec_mid_kernel(const DecFusedFwd a) {
     const float* src = i < D ? p.b_co + i : i < 2 * D ? p.g2 + (i - D) : i < 3 * D ? p.be2 + (i - 2 * D) : p.b_1 + c0 * HC + (i - 3 * D);
     vv[k] = *src;
   }
-  order_point();   // the small loads are requested first: they are returned first
   load_w<1, 4>(wo, (const bf16*)p.f_co, wave, D / 32, 0, lane);
   load_res(res, (const bf16*)s.x1 + (size_t)m0 * D, T, tid);
+  // The feed-forward weights (256 KiB per workgroup, every workgroup of the chip at once) are requested only when the
+  // few loads the first phases wait for have come back: behind that burst they would take as long as the burst.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const bf16* const W1 = (const bf16*)p.f_1;
   const bf16* const W2 = (const bf16*)p.f_2;
   ffn_load_w(w1A, w2A, W1, W2, c0, wave, lane);
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
   } else {
     rows_issue(rv, (const bf16*)s.x + (size_t)m0 * D, T, tid);
   }
-  order_point();
+  if constexpr (do_tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in the middle kernel
+  else order_point();
   bf16x8 wq[3][4], wo[1][4], wc[1][4];
   if constexpr (HEAD) {
 #pragma unroll
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
       for (int e = 0; e < 4; ++e) z[4 * j + e] = bv[e] + ((part[0][j][e] + part[1][j][e]) + (part[2][j][e] + part[3][j][e]));
     }
     static_assert(DEC_FFN_PARTS == 4, "sum of the partial sums");
-    if (dp > 0.f) {
+    {
       const uint32_t idx = (uint32_t)(m0 + t_) * 128u + (uint32_t)c0_;
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) { pv[kt][i] = __builtin_amdgcn_exp2f(pv[kt][i] - mx); l += pv[kt][i]; }
         l = xor32_sum(l);
-        if (dp > 0.f) {
+        {
           const uint32_t rs = attn_row_seed(a.seed_h + 0, (uint32_t)((b * 16 + hh) * T + q));
 #pragma unroll
           for (int kt = 0; kt <= qt; ++kt)

@@ -44,6 +44,12 @@ class GradReducer:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
         self.works = []
+        # what the last step sent: collectives issued, bytes reduced; exposed wait of finish() as a pair of events
+        # on the stream that waited (device tensors) or as host seconds (CPU tensors, host-staged rehearsal)
+        self.collectives = 0
+        self.bytes_reduced = 0
+        self.wait_events = None
+        self.wait_host_s = 0.0
 
     def on_segment(self, name, also=()):
         """`also`: the engine's weight-gradient stream (its already-enqueued work writes this segment)."""
@@ -54,36 +60,72 @@ class GradReducer:
             pieces = [(lo, hi)]
         else:
             pieces = [(max(lo, a), min(hi, b)) for a, b in self.active if max(lo, a) < min(hi, b)]
-        for a, b in pieces:
-            self._reduce(self.flat[a:b], also)
+        if pieces:
+            # the pieces of one segment (a segment is cut where an inactive parameter range lies inside it) go out as
+            # ONE collective
+            self._reduce([self.flat[a:b] for a, b in pieces], also)
 
-    def _reduce(self, view, also):
+    def _reduce(self, views, also):
         side = next((s for s in also if s is not None), None) if self.cuda else None
+        self.collectives += 1
+        self.bytes_reduced += sum(v.numel() * v.element_size() for v in views)
+
+        def issue():
+            if len(views) == 1:
+                return dist.all_reduce(views[0], op=dist.ReduceOp.SUM, async_op=True)
+            return dist.all_reduce_coalesced(views, op=dist.ReduceOp.SUM, async_op=True)
+
         if self.cuda and dist.get_backend() == "gloo":
             # single-GPU rehearsal of the multi-rank path (several ranks on one card): stage through the host,
             # synchronously -- this exercises the segment bookkeeping, not the overlap
+            t0 = time.perf_counter()
             if side is not None:
                 side.synchronize()
             torch.cuda.current_stream().synchronize()
-            host = view.cpu()
+            host = torch.cat([v.reshape(-1) for v in views]).cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            view.copy_(host)
+            off = 0
+            for v in views:
+                v.copy_(host[off:off + v.numel()])
+                off += v.numel()
+            self.wait_host_s += time.perf_counter() - t0
         elif side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                self.works.append(issue())
         else:
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self.works.append(issue())
+
+    def begin_step(self):
+        self.collectives, self.bytes_reduced, self.wait_events, self.wait_host_s = 0, 0, None, 0.0
 
     def finish(self):
         """Wait for the segment reductions (device tensors: the current stream waits, not the host); the caller
-        scales by 1/world (fused into the optimizer)."""
+        scales by 1/world (fused into the optimizer).  The wait is bracketed by two events on the waiting stream (device
+        tensors) or timed on the host: what a step spends here is the part of the reductions that backward did not hide."""
+        timed = self.cuda and bool(self.works)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
         for i, w in enumerate(self.works):
             if os.environ.get("MMST_DEBUG_REDUCE"):
                 print(f"[reduce] rank {dist.get_rank()} waits for segment work {i} of {len(self.works)}", flush=True)
             w.wait()
+        if timed:
+            e1.record()
+            self.wait_events = (e0, e1)
+        else:
+            self.wait_host_s += time.perf_counter() - t0
         self.works = []
         return 1.0 / self.world
+
+    def exposed_wait_ms(self):
+        """Milliseconds the last step's finish() held the compute stream (or the host) up; call after a synchronize."""
+        ms = 1000.0 * self.wait_host_s
+        if self.wait_events is not None:
+            ms += self.wait_events[0].elapsed_time(self.wait_events[1])
+        return ms
 
 
 class FusedAdamW:
@@ -209,6 +251,7 @@ class TransformerMultiGPU:
         if self.reducer is None or self.reducer.flat is not ar.G:
             self.reducer = GradReducer(ar.G, ar.reduce_segments(), self.world,
                                        active=ar.active_ranges(self.config.training_mode))
+        self.reducer.begin_step()
         if os.environ.get("MMST_C_STEP", "1") != "0" and not getattr(self.config, "use_real_data", False):
             # the whole step in one call into the library (mmst_train_step); with several ranks the optimizer runs
             # after the segment reductions have been waited for

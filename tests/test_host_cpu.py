@@ -286,6 +286,11 @@ red2.finish()
 i = torch.arange(n)
 act = ((i >= 100) & (i < 450)) | ((i >= 650) & (i < 900))
 assert torch.equal(flat2, torch.where(act, want, torch.arange(n, dtype=torch.float32) * (rank + 1)))
+# the two pieces of the cross segment (400..450, 650..700) went out as ONE collective: three per step, 600 floats
+assert red2.collectives == 3 and red2.bytes_reduced == 4 * 600, (red2.collectives, red2.bytes_reduced)
+assert red2.exposed_wait_ms() >= 0.0
+red2.begin_step()
+assert red2.collectives == 0 and red2.bytes_reduced == 0
 # every molecule is seen exactly once per epoch across ranks (up to wrap-around padding)
 idx = shard_indices(37, rank, world)
 gathered = [None] * world
