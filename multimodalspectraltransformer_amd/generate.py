@@ -164,7 +164,11 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
 
     def enqueue(pos, select):
         if fused:
-            if keep_logits is not None:   # this position's logits go to row `pos` of the caller's [max_len][B][64] buffer
+            # this position's logits go straight to row `pos` of the caller's [max_len][B][64] buffer -- but never under
+            # graph capture or replay: a captured launch keeps the pointer it was captured with, so there the logits
+            # always land in the plan's own buffer and are copied out behind the replay
+            direct = keep_logits is not None and not use_graph
+            if direct:
                 stt.stack.logits = keep_logits[pos].data_ptr()
             stt.stack_step(tok[pos].data_ptr(), pe, pos, tok[pos + 1].data_ptr() if select else None,
                            prob[pos].data_ptr() if select else None, temperature)
@@ -182,7 +186,7 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
             L.check(lib.mmst_greedy_select(C.c_void_p(stt.logits.data_ptr()), VPAD, model.out_size, B, 1,
                                            C.c_float(float(temperature)), C.c_void_p(tok[pos + 1].data_ptr()),
                                            C.c_void_p(prob[pos].data_ptr()), st()), "mmst_greedy_select")
-        if keep_logits is not None:
+        if keep_logits is not None and not use_graph:
             keep_logits[pos].copy_(stt.logits)
 
     steps = 0
@@ -197,8 +201,12 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
                     enqueue(pos, True)
                 stt.graphs[key] = g
             g.replay()
+            if keep_logits is not None:
+                keep_logits[pos].copy_(stt.logits)
         else:
             enqueue(pos, not sample)
+            if use_graph and keep_logits is not None:
+                keep_logits[pos].copy_(stt.logits)
             if sample:
                 p = torch.softmax(stt.logits[:, :model.out_size] / temperature, dim=1)
                 nxt = torch.multinomial(p, 1, generator=generator).squeeze(1)
@@ -554,7 +562,10 @@ def _plan_for(model, memory):
     """The plan whose buffers hold `memory`.  Tensors handed out by MultimodalTransformer.forward()/run_model() carry
     their plan and the serial number of the encoder pass that produced them; a plan that has been re-encoded since
     (another batch of the same shape) no longer holds this memory, and decoding it would silently use the newer
-    batch, so that is refused.  Tensors without the stamp (clones) fall back to the model's last plan."""
+    batch, so that is refused.  A tensor without the stamp (a clone, a copy on another device, a slice put together
+    again) is accepted only if it IS the memory of the model's last plan: 64 sampled elements must equal the plan's
+    (the reference's decode functions read the tensor they are given; here the tensor names the buffers to read, so one
+    with other contents is refused instead of being ignored)."""
     stamp = getattr(memory, "_mmst_plan", None)
     if stamp is not None:
         pl, serial = stamp
@@ -563,6 +574,17 @@ def _plan_for(model, memory):
                               "later run_model()/forward() call of the same shape")
     else:
         pl = getattr(model, "_last_plan", None)
-    if pl is None or memory.shape[1] != pl.B or memory.shape[0] != pl.Lmem:
+    if pl is None or memory.dim() != 3 or memory.shape[1] != pl.B or memory.shape[0] != pl.Lmem or memory.shape[2] != D:
         raise L.MMSTError("decoding needs the plan of the preceding run_model()/forward() call")
+    if stamp is None:
+        Lm, B = pl.Lmem, pl.B
+        n = Lm * B * D
+        idx = torch.linspace(0, n - 1, 64, device=pl.eng.device).long()
+        l, b, d = idx // (B * D), (idx // D) % B, idx % D
+        held = pl.cv.view(pl.memory, B, Lm, D)[b, l, d].float()
+        given = memory.to(pl.eng.device)[l, b, d].float()
+        if not bool(((held - given).abs() <= 1e-6 + 2e-3 * held.abs()).all()):
+            raise L.MMSTError("this memory tensor is not the encoder output held by the model's last plan: decode "
+                              "functions read the plan's buffers, so a tensor with other contents cannot be decoded "
+                              "(run run_model()/forward() on the batch it belongs to first)")
     return pl
