@@ -176,7 +176,9 @@ int mmst_decoder_layer_step(const mmst_dec_params* p, const mmst_dec_step* s, in
  * row and the caches.  Limits: B <= MMST_STATIC_STEP_MAX_B (larger B returns -1, nothing is launched); the array
  * (about 2.3 MB) exists once per GPU for the life of the process and is shared by every call on that GPU, so two calls
  * that overlap on one GPU (different streams or threads) race -- serialise them.  The call itself allocates nothing
- * and frees nothing; its results equal mmst_decoder_layer_step's bit for bit. */
+ * and frees nothing; its results equal mmst_decoder_layer_step's bit for bit.  The FIRST call on a device looks the
+ * array's address up (hipGetSymbolAddress, which may load the code object): make one eager call per device before
+ * capturing the entry point into a HIP graph. */
 #define MMST_STATIC_STEP_MAX_B 256
 int mmst_decoder_layer_step_static(const mmst_dec_params* p, const void* x, void* y, void* qkv_cache, const void* kvc,
                                    const float* mem_bias, int B, int pos, int cap, int L, int nhead, void* stream);

@@ -129,7 +129,7 @@ int mmst_beam_init(const mmst_beam_state* st, int64_t* tok, int B, int W, int ca
 int mmst_beam_step(const float* logits, int ld_logits, int V, const mmst_beam_state* cur, const mmst_beam_state* next,
                    int64_t* tok, int B, int W, int cap, int pos, int eos, void* stream) {
   if (!logits || !state_ok(cur) || !state_ok(next) || !tok || B < 1 || W < 1 || W > MAXW || V < W || V > 64 ||
-      ld_logits < V || pos < 0 || pos + 2 > cap)
+      ld_logits < V || pos < 0 || pos >= cap)   // the step writes seqs[.][pos + 1] (of cap + 1), probs[.][pos], hist[.][< cap]
     return MMST_ERR_ARG;
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld_logits, V, *cur, *next, tok,
                      W, cap, pos, eos);

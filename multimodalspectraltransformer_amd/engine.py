@@ -690,6 +690,8 @@ class Engine:
                                            C.c_void_p(ar.p32("pe_trg.weight")), C.c_void_p(_P(pl.trg_emb)), B, T,
                                            C.c_float(p_drop2), C.c_uint32(self.layer_seed(100)), st),
                     "mmst_trg_embed_fwd")
+        if ar.transposed_ready is not None:   # fragment-major weight images refreshed on the second stream
+            torch.cuda.current_stream().wait_event(ar.transposed_ready)
         ndl = m.num_decoder_layers
         pp = (C.c_void_p * ndl)(*[C.addressof(pl.dec_p[l]) for l in range(ndl)])
         aa = (C.c_void_p * ndl)(*[C.addressof(pl.dec_a[l]) for l in range(ndl)])
@@ -870,7 +872,16 @@ class Engine:
         else:
             a.adam_step, a.lr, (a.beta1, a.beta2), a.eps, a.weight_decay = adam
         a.grad_scale = float(grad_scale)
-        cb = L.SEGMENT_CALLBACK(on_segment) if on_segment is not None else L.SEGMENT_CALLBACK()
+        failure = []
+
+        def guarded(seg, user):   # an exception must not vanish inside the foreign-function callback
+            try:
+                on_segment(seg, user)
+            except BaseException as e:  # noqa: BLE001
+                if not failure:
+                    failure.append(e)
+
+        cb = L.SEGMENT_CALLBACK(guarded) if on_segment is not None else L.SEGMENT_CALLBACK()
         a.on_segment = cb
         main = torch.cuda.current_stream()
         ws = self._side_stream(main)
@@ -880,7 +891,14 @@ class Engine:
         self.arena.grads_zeroed = False
         L.check(L.lib().mmst_train_step(C.byref(sp), C.byref(a), C.c_void_p(main.cuda_stream),
                                         C.c_void_p(ws.cuda_stream)), "mmst_train_step")
+        if failure:
+            raise failure[0]   # e.g. a collective that failed in a segment callback: the step must not go on unreduced
         self.arena.grads_zeroed = adam is not None   # the fused optimizer clears what it has consumed
+        if adam is not None:
+            # the step refreshed the transposed weights and the fragment-major images on the second stream: whoever reads
+            # them outside mmst_train_step (Engine.decode, Engine.backward) waits for this event first
+            self.arena.transposed_ready = torch.cuda.Event()
+            self.arena.transposed_ready.record(ws)
         return pl.cv.view(pl.loss, 1)
 
     def _side_stream(self, main):

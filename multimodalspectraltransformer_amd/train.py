@@ -396,7 +396,12 @@ class TransformerMultiGPU:
         opt.lr, opt.betas, opt.eps, opt.wd = ost["lr"], tuple(ost["betas"]), ost["eps"], ost["weight_decay"]
         opt.step_count = int(ost["step"])
         if "exp_avg" in ost:
-            ar.M, ar.V = torch.zeros_like(ar.P), torch.zeros_like(ar.P)
+            # in place when the moment buffers exist: a step plan built earlier holds their addresses
+            if ar.M is None:
+                ar.M, ar.V = torch.zeros_like(ar.P), torch.zeros_like(ar.P)
+            else:
+                ar.M.zero_()
+                ar.V.zero_()
             for k in ar.order:
                 ar.M[ar.offset[k]: ar.offset[k] + ar.numel[k]].copy_(ost["exp_avg"][k].reshape(-1))
                 ar.V[ar.offset[k]: ar.offset[k] + ar.numel[k]].copy_(ost["exp_avg_sq"][k].reshape(-1))

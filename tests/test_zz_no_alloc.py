@@ -79,3 +79,39 @@ def test_static_scratch_token_step_equals_the_allocating_one():
     assert rc != 0 and float(y.float().min()) == 3.0
     assert fn(C.cast(C.byref(P[0]), C.c_void_p), x.data_ptr(), y.data_ptr(), cache.data_ptr(), kvc.data_ptr(), None,
               0, 0, 4, 8, NH, L.stream_ptr()) != 0
+
+
+def test_static_scratch_token_step_under_graph_capture():
+    """The use the entry point exists for: after ONE eager call on the device (which resolves the address of the static
+    array; that query must not happen while a stream is capturing) the call is captured into a HIP graph and
+    replayed; the replay writes the same bits as the eager call."""
+    gen = torch.Generator(device="cuda").manual_seed(78)
+    layer = _layer_params(gen, "cuda")
+    B, pos, cap, Lm = 48, 5, 16, 130
+    ya, yb, ca, cb, c0 = _both(layer, B, pos, cap, Lm, gen, True)      # eager warm-up (and the reference result)
+    assert torch.equal(ya, yb)
+    dev = "cuda"
+    g2 = torch.Generator(device="cuda").manual_seed(78)
+    layer2 = _layer_params(g2, dev)                                       # same parameters, same inputs as _both drew
+    r = lambda *s: torch.randn(*s, generator=g2, device=dev)  # noqa: E731
+    x = (r(B, D) * 0.8).bfloat16()
+    cache = (r(B, cap, 3 * D) * 0.7).bfloat16()
+    kvc = (r(B, Lm, 2 * D) * 0.7).bfloat16()
+    bias = torch.zeros(B, Lm, device=dev)
+    bias[:, Lm // 3:Lm // 3 + 2] = float("-inf")
+    bias[:, -1] = 1.0
+    y = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+    P = _params_array([layer2])
+    fn = L.lib().mmst_decoder_layer_step_static
+    fn.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = fn(C.cast(C.byref(P[0]), C.c_void_p), x.data_ptr(), y.data_ptr(), cache.data_ptr(), kvc.data_ptr(),
+                bias.data_ptr(), B, pos, cap, Lm, NH, L.stream_ptr())
+    assert rc == 0
+    for _ in range(2):
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ya), float((y.float() - ya.float()).abs().max())
+        assert torch.equal(cache, ca)
