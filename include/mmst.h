@@ -285,6 +285,15 @@ int mmst_decoder_layer_bwd_streams(const mmst_dec_params* p, const mmst_dec_grad
                                    const mmst_dec_bwd* w, int nhead, float drop_p, uint32_t seed, int join_dmem,
                                    void* stream, void* wstream);
 
+/* The whole decoder backward on two streams, layers nl - 1 .. 0: what nl calls of mmst_decoder_layer_bwd_streams do
+ * from the top layer down (join_dmem set for layer 0), with w[l]->dx = w[l - 1]->dz3 (and dxd = dzd3), w[l]->prev_* =
+ * layer l - 1's norm3 and w[l]->prev_seed = seeds[l - 1].  For target sequences of at most 64 positions under the causal
+ * mask, with the fragment-major transposed weight images (mmst_dec_params.ft_*) present, the activation gradients of a
+ * layer take five launches instead of nine; same results to bf16 rounding (what autograd does for :963). */
+int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, const mmst_dec_grads* const* g,
+                                   const mmst_dec_acts* const* a, const mmst_dec_bwd* const* w, int nhead, float drop_p,
+                                   const uint32_t* seeds, void* stream, void* wstream);
+
 /* Standalone LayerNorm backward (top of a layer stack): dy -> dz / dzd, accumulates dgamma, dbeta.
  * dy row (b, s) is read at row b*dy_L + dy_off + s when dy_L > 0 (a slice of the concatenated memory). */
 int mmst_layernorm_bwd(int rows, const void* dy, int dy_S, int dy_L, int dy_off, const void* z, const float* stats,

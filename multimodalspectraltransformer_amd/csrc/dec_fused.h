@@ -24,5 +24,37 @@ struct DecFusedFwd {
 };
 #define DEC_FFN_PARTS 4   // workgroups per molecule that share the hidden dimension of the feed-forward block
 int launch_dec_fused_fwd(const DecFusedFwd& a, hipStream_t stream);
+
+// Backward, activation gradients (the parameter gradients stay with the grouped split-K launches that read what these
+// kernels store).  Per layer, from its incoming gradient (dz3, dzd3):
+//   mid : [optionally first: (dz3, dzd3) of THIS layer = LayerNorm-3 backward of (dqkv' Wqkv' + dz1') of the layer above]
+//         dh = ((dzd3 W2) * mask(h)) / (1 - p), partial sums of dh W1 per hidden quarter -> workspace
+//   ln  : (dz2, dzd2) = LayerNorm-2 backward of (sum of the partial sums + dz3); da2 = dzd2 Wco
+//         ... cross-attention backward (attn.hip) gives dqc ...
+//   ln  : (dz1, dzd1) = LayerNorm-1 backward of (dqc Wcq + dz2); da = dzd1 Wo
+//         ... self-attention backward (attn.hip) gives dqkv; the layer below (or a GEMM launch) turns it into its dz3
+struct DecFusedBwd {
+  mmst_dec_params p; mmst_dec_grads g; mmst_dec_acts a; mmst_dec_bwd w;   // this layer
+  uint32_t seed;            // this layer's dropout seed
+  const void* up_dqkv;      // layer above: dqkv' [B*T][384], or NULL (then w.dz3 / w.dzd3 are read)
+  const void* up_dz1;       //              dz1' (the residual)
+  const void* up_ft_qkv;    //              fragment-major image of Wqkv'^T
+  int B, T;
+  float drop_p;
+  float* ws;                // fp32 [DEC_FFN_PARTS][B*T][128]
+};
+struct DecFusedLn {
+  const float* ws;          // partial sums to add up (then `in` / ft_in are unused), or NULL
+  const void* in; const void* ft_in;     // input rows [B*T][128] and the image of the transposed weight they go through
+  const void* res;          // residual gradient rows added to it
+  const void* z; const float* stats; const float* gamma; float* dgamma; float* dbeta;   // the LayerNorm
+  void* dz; void* dzd;      // out: gradient at the pre-norm sum, the same through the dropout mask (seed)
+  const void* ft_out; void* out;         // out = dzd Wout (image of Wout^T)
+  uint32_t seed;
+  int B, T;
+  float drop_p;
+};
+int launch_dec_bwd_mid(const DecFusedBwd& a, hipStream_t stream);
+int launch_dec_bwd_ln(const DecFusedLn& a, hipStream_t stream);
 bool dec_fused_enabled();   // environment MMST_DEC_FUSED (default on), or what dec_fused_set() said last
 void dec_fused_set(int on);  // 1 / 0; negative: back to the default

@@ -604,6 +604,333 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
   STAMP(7);
 }
 
+
+// =====================================================================================================================
+// Backward (activation gradients).  Same arrangement as the forward kernels; the weight side of every GEMM is the
+// fragment-major image of the TRANSPOSED weight (dX = dY W has W^T as its [out][contraction] operand).
+// =====================================================================================================================
+
+// acc of a 128-column product (the wave's 16 columns from n0) as it stands -> fp32 scratch
+__device__ __forceinline__ void acc_to_scratch(const f32x4 (&acc)[1][4], float* Zf, int n0, int lane) {
+  const int r = lane & 15, g = lane >> 4, n = n0 + 4 * g;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(Zf + (mt * 16 + r) * ZS + n) = acc[0][mt];
+}
+
+// LayerNorm backward for the lane's 16 columns of row t (8 consecutive lanes share a row): dy -> dz; the lane's
+// contributions to dgamma / dbeta are ADDED to pg / pb.  zr: the saved pre-norm row (bf16), gamma: 128 floats in LDS.
+__device__ __forceinline__ void lnbwd_core(const float (&dy)[16], const bf16x8 (&zr)[2], float mean, float rstd, const float* gamma,
+                                           int c0, bool ok, float (&dz)[16], float (&pg)[16], float (&pb)[16]) {
+  float xh[16], gy[16];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0 + 4 * j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * j + e;
+      xh[i] = ok ? ((float)zr[i >> 3][i & 7] - mean) * rstd : 0.f;
+      gy[i] = dy[i] * gv[e];
+      s1 += gy[i];
+      s2 += gy[i] * xh[i];
+    }
+  }
+  s1 = row8_sum(s1) * (1.0f / 128.0f);
+  s2 = row8_sum(s2) * (1.0f / 128.0f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    dz[i] = rstd * (gy[i] - s1 - xh[i] * s2);
+    pg[i] += dy[i] * xh[i];
+    pb[i] += dy[i];
+  }
+}
+// column sums of pg / pb over the workgroup's 64 rows -> atomically into dgamma / dbeta.  red: 8 KiB of LDS free of live data.
+__device__ __forceinline__ void lnbwd_colsums(float (&pg)[16], float (&pb)[16], float* dgamma, float* dbeta, float* red, int tid,
+                                              bool store) {
+  const int lane = tid & 63, wave = tid >> 6;
+  // the 8 rows of a wave are the lanes with equal lane & 7: rotate by 8 inside the row of 16 lanes, then across the rows
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    pg[i] += dpp_f32<0x128>(pg[i]);   // row_ror:8
+    pb[i] += dpp_f32<0x128>(pb[i]);
+    pg[i] = xor32_sum(xor16_sum(pg[i]));
+    pb[i] = xor32_sum(xor16_sum(pb[i]));
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      red[(wave * 2 + 0) * 128 + lane * 16 + i] = pg[i];
+      red[(wave * 2 + 1) * 128 + lane * 16 + i] = pb[i];
+    }
+  }
+  lds_barrier();
+  if (store && tid < 256) {
+    const int which = tid >> 7, col = tid & 127;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[(w * 2 + which) * 128 + col];
+    atomicAdd((which ? dbeta : dgamma) + col, s);
+  }
+}
+// dz (16 columns of row t) -> memory as bf16, and through the element dropout of the forward's row epilogue (pair hash of
+// element index m * 128 + n) into an LDS image and memory
+__device__ __forceinline__ void store_dz(const float (&dz)[16], bf16* dz_g, bf16* dzd_g, unsigned char* dzd_img, int m, int t, int c0,
+                                         bool store, uint32_t seed, uint32_t thr, float dscale) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    bf16x8 a, d;
+    const uint32_t idx = (uint32_t)m * 128u + (uint32_t)(c0 + 8 * j);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const uint32_t h = drop_bits(seed, (idx + e) >> 1);
+      const float v0 = dz[8 * j + e], v1 = dz[8 * j + e + 1];
+      a[e] = (bf16)v0;
+      a[e + 1] = (bf16)v1;
+      d[e] = (bf16)(((h & 0xFFFFu) >= thr) ? v0 * dscale : 0.f);
+      d[e + 1] = (bf16)(((h >> 16) >= thr) ? v1 * dscale : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(dzd_img + t * XS + (c0 + 8 * j) * 2) = d;
+    if (store) {
+      *reinterpret_cast<bf16x8*>(dz_g + (size_t)t * D + c0 + 8 * j) = a;
+      if (dzd_g) *reinterpret_cast<bf16x8*>(dzd_g + (size_t)t * D + c0 + 8 * j) = d;
+    }
+  }
+}
+
+// ---- feed-forward block backward, row-local, this workgroup's quarter of the hidden dimension:
+//   [PRO: dy3 = dqkv' Wqkv' + dz1' (the layer ABOVE, primed), (dz3, dzd3) = LayerNorm-3 backward of this layer]
+//   dh = ((dzd3 W2) * mask(h)) / (1 - p)  (stored for the weight gradients),  partial sums of dh W1 -> workspace ----
+constexpr int BU_BYTES = TM * QS + TM * ZS * 4;   // dqkv image + fp32 scratch; later the two hidden-chunk images
+static_assert(BU_BYTES >= 2 * TM * HS, "union region of the backward middle kernel");
+template <bool PRO>
+__global__ __launch_bounds__(NTHR) void dec_bwd_mid_kernel(const DecFusedBwd a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + BU_BYTES + (D + 2048) * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / DEC_FFN_PARTS, part = blockIdx.x % DEC_FFN_PARTS, T = a.T, m0 = b * T;
+  const float dp = a.drop_p;
+  const uint32_t thr = drop_threshold(dp);
+  const float dscale = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  const mmst_dec_params& p = a.p;
+  const mmst_dec_acts& s = a.a;
+  const mmst_dec_bwd& w = a.w;
+  unsigned char* const D3 = smem;                 // dzd3 rows
+  unsigned char* const U = smem + X_BYTES;
+  float* const Zf = reinterpret_cast<float*>(U + TM * QS);
+  float* const vec = reinterpret_cast<float*>(smem + X_BYTES + BU_BYTES);   // gamma3
+  float* const red = vec + D;
+  constexpr int CPP = FF / HC / DEC_FFN_PARTS;
+  const int c0 = part * CPP;
+  const int t_ = tid >> 3, c0_ = (tid & 7) * 16;
+  const bool ok_ = t_ < T;
+  const bf16* const dzd3_g = (const bf16*)(dp > 0.f ? w.dzd3 : w.dz3);
+  bf16x8 w1A[2][4], w2A[1][8], w1B[2][4], w2B[1][8];
+  if constexpr (PRO) {
+    // small loads first: the rows of dqkv', the residual dz1', this layer's saved z3 and statistics, gamma3, Wqkv'^T
+    uint4 qv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = tid + k * NTHR, t = i / 48, c = i % 48;
+      qv[k] = *reinterpret_cast<const uint4*>((const bf16*)a.up_dqkv + (size_t)(m0 + (t < T ? t : T - 1)) * 3 * D + c * 8);
+    }
+    bf16x8 res[2], zr[2];
+    load_res(res, (const bf16*)a.up_dz1 + (size_t)m0 * D, T, tid);
+    load_res(zr, (const bf16*)s.z3 + (size_t)m0 * D, T, tid);
+    const float mean = s.st3[2 * (size_t)(m0 + (ok_ ? t_ : T - 1))], rstd = s.st3[2 * (size_t)(m0 + (ok_ ? t_ : T - 1)) + 1];
+    const float gv = p.g3[tid & 127];
+    bf16x8 wq[1][12];
+    load_w<1, 12>(wq, (const bf16*)a.up_ft_qkv, wave, 3 * D / 32, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ffn_load_w(w1A, w2A, (const bf16*)p.ft_2, (const bf16*)p.ft_1, c0, wave, lane);
+    ffn_load_w(w1B, w2B, (const bf16*)p.ft_2, (const bf16*)p.ft_1, c0 + 1, wave, lane);
+    order_point();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = tid + k * NTHR, t = i / 48, c = i % 48;
+      *reinterpret_cast<uint4*>(U + t * QS + c * 16) = t < T ? qv[k] : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < D) vec[tid] = gv;
+    lds_barrier();
+    {
+      f32x4 acc[1][4];
+      zero_acc<1>(acc);
+      mma_tok<1, 12>(acc, wq, U, QS, lane);
+      acc_to_scratch(acc, Zf, 16 * wave, lane);
+    }
+    lds_barrier();
+    float dy[16], dz[16], pg[16], pb[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Zf + t_ * ZS + c0_ + 4 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        dy[i] = ok_ ? v[e] + (float)res[i >> 3][i & 7] : 0.f;
+        pg[i] = 0.f;
+        pb[i] = 0.f;
+      }
+    }
+    lnbwd_core(dy, zr, mean, rstd, vec, c0_, ok_, dz, pg, pb);
+    store_dz(dz, (bf16*)w.dz3 + (size_t)m0 * D, dp > 0.f ? (bf16*)w.dzd3 + (size_t)m0 * D : nullptr, D3, m0 + t_, t_, c0_,
+             ok_ && part == 0, a.seed + 5, thr, dscale);
+    lnbwd_colsums(pg, pb, a.g.g3, a.g.be3, red, tid, part == 0);   // (its barrier also completes the dzd3 image)
+  } else {
+    uint4 rv[2];
+    rows_issue(rv, dzd3_g + (size_t)m0 * D, T, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ffn_load_w(w1A, w2A, (const bf16*)p.ft_2, (const bf16*)p.ft_1, c0, wave, lane);
+    ffn_load_w(w1B, w2B, (const bf16*)p.ft_2, (const bf16*)p.ft_1, c0 + 1, wave, lane);
+    order_point();
+    rows_commit(D3, rv, T, tid);
+    lds_barrier();
+  }
+  // ---- two chunks of 256 hidden columns: the saved activation's chunk is staged into the chunk image, the epilogue
+  // replaces each entry by its gradient in place ----
+  const bf16* const Hg = (const bf16*)s.h + (size_t)m0 * FF;
+  bf16* const dHg = (bf16*)w.dh + (size_t)m0 * FF;
+  f32x4 acc2[1][4];
+  zero_acc<1>(acc2);
+#pragma unroll
+  for (int cc = 0; cc < CPP; ++cc) {
+    const int c = c0 + cc;
+    unsigned char* const Hc = U + cc * (TM * HS);
+    uint4 hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * NTHR, t = i >> 5, q = i & 31;
+      hv[k] = *reinterpret_cast<const uint4*>(Hg + (size_t)(t < T ? t : T - 1) * FF + c * HC + q * 8);
+    }
+    f32x4 acc1[2][4];
+    zero_acc<2>(acc1);
+    if (cc == 0) mma_tok<2, 4>(acc1, w1A, D3, XS, lane);
+    else mma_tok<2, 4>(acc1, w1B, D3, XS, lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * NTHR, t = i >> 5, q = i & 31;
+      *reinterpret_cast<uint4*>(Hc + t * HS + q * 16) = hv[k];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int lc = 32 * wave + nt * 16 + 4 * g;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        unsigned char* const hp = Hc + (mt * 16 + r) * HS + lc * 2;
+        const uint2 hb = *reinterpret_cast<const uint2*>(hp);
+        float v[4];
+        v[0] = (hb.x & 0xFFFFu) ? acc1[nt][mt][0] * dscale : 0.f;   // saved entries are >= 0: nonzero bits = positive
+        v[1] = (hb.x >> 16) ? acc1[nt][mt][1] * dscale : 0.f;
+        v[2] = (hb.y & 0xFFFFu) ? acc1[nt][mt][2] * dscale : 0.f;
+        v[3] = (hb.y >> 16) ? acc1[nt][mt][3] * dscale : 0.f;
+        *reinterpret_cast<uint2*>(hp) = pack4(v);
+      }
+    }
+    lds_barrier();
+    for (int i = tid; i < TM * 32; i += NTHR) {
+      const int t = i >> 5, q = i & 31;
+      if (t < T) *reinterpret_cast<uint4*>(dHg + (size_t)t * FF + c * HC + q * 8) = *reinterpret_cast<const uint4*>(Hc + t * HS + q * 16);
+    }
+    if (cc == 0) mma_tok<1, 8>(acc2, w2A, Hc, HS, lane);
+    else mma_tok<1, 8>(acc2, w2B, Hc, HS, lane);
+  }
+  float* const ws = a.ws + ((size_t)part * a.B * T + m0) * D;
+  const int n = 16 * wave + 4 * g;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int t = mt * 16 + r;
+    if (t < T) *reinterpret_cast<f32x4*>(ws + (size_t)t * D + n) = acc2[0][mt];
+  }
+}
+
+// ---- LayerNorm backward between two projections, one workgroup per molecule:
+//   dy = (PARTS ? sum of the feed-forward partial sums : in Win) + residual;  (dz, dzd) = LayerNorm backward;
+//   out = dzd Wout.   PARTS: norm2 (in front of the cross-attention's out_proj);  otherwise norm1 with in = dqc ----
+template <bool PARTS>
+__global__ __launch_bounds__(NTHR) void dec_bwd_ln_kernel(const DecFusedLn a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + TM * ZS * 4 + (D + 2048) * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, T = a.T, m0 = b * T;
+  const float dp = a.drop_p;
+  const uint32_t thr = drop_threshold(dp);
+  const float dscale = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  unsigned char* const IN = smem;                 // input rows of the first projection
+  unsigned char* const DZ = smem + X_BYTES;       // dzd rows
+  float* const Zf = reinterpret_cast<float*>(smem + 2 * X_BYTES);
+  float* const vec = reinterpret_cast<float*>(smem + 2 * X_BYTES + TM * ZS * 4);
+  float* const red = vec + D;
+  const int t_ = tid >> 3, c0_ = (tid & 7) * 16;
+  const bool ok_ = t_ < T;
+  const size_t row = (size_t)(m0 + (ok_ ? t_ : T - 1));
+  f32x4 part[DEC_FFN_PARTS][4];
+  uint4 rv[2];
+  if constexpr (PARTS) {
+#pragma unroll
+    for (int q = 0; q < DEC_FFN_PARTS; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        part[q][j] = *reinterpret_cast<const f32x4*>(a.ws + ((size_t)q * a.B * T + row) * D + c0_ + 4 * j);
+  } else {
+    rows_issue(rv, (const bf16*)a.in + (size_t)m0 * D, T, tid);
+  }
+  bf16x8 res[2], zr[2];
+  load_res(res, (const bf16*)a.res + (size_t)m0 * D, T, tid);
+  load_res(zr, (const bf16*)a.z + (size_t)m0 * D, T, tid);
+  const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+  const float gv = a.gamma[tid & 127];
+  bf16x8 wi[1][4], wo[1][4];
+  if constexpr (!PARTS) load_w<1, 4>(wi, (const bf16*)a.ft_in, wave, D / 32, 0, lane);
+  load_w<1, 4>(wo, (const bf16*)a.ft_out, wave, D / 32, 0, lane);
+  order_point();
+  if (tid < D) vec[tid] = gv;
+  float dy[16], dz[16], pg[16], pb[16];
+  if constexpr (!PARTS) {
+    rows_commit(IN, rv, T, tid);
+    lds_barrier();
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_tok<1, 4>(acc, wi, IN, XS, lane);
+    acc_to_scratch(acc, Zf, 16 * wave, lane);
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Zf + t_ * ZS + c0_ + 4 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dy[4 * j + e] = v[e];
+    }
+  } else {
+    lds_barrier();   // gamma staged
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dy[4 * j + e] = (part[0][j][e] + part[1][j][e]) + (part[2][j][e] + part[3][j][e]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    dy[i] = ok_ ? dy[i] + (float)res[i >> 3][i & 7] : 0.f;
+    pg[i] = 0.f;
+    pb[i] = 0.f;
+  }
+  lnbwd_core(dy, zr, mean, rstd, vec, c0_, ok_, dz, pg, pb);
+  store_dz(dz, (bf16*)a.dz + (size_t)m0 * D, dp > 0.f ? (bf16*)a.dzd + (size_t)m0 * D : nullptr, DZ, m0 + t_, t_, c0_, ok_, a.seed, thr,
+           dscale);
+  lnbwd_colsums(pg, pb, a.dgamma, a.dbeta, red, tid, true);   // (its barrier also completes the dzd image)
+  {
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_tok<1, 4>(acc, wo, DZ, XS, lane);
+    const int n = 16 * wave + 4 * g;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int t = mt * 16 + r;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[0][mt][e];
+      if (t < T) *reinterpret_cast<uint2*>((bf16*)a.out + (size_t)(m0 + t) * D + n) = pack4(v);
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -624,6 +951,21 @@ int launch_dec_fused_fwd(const DecFusedFwd& a, hipStream_t stream) {
   if (a.do_tail && a.do_head) MMST_LAUNCH((dec_head_kernel<true, true>), dim3(a.B), dim3(NTHR), 0, stream, a);
   else if (a.do_tail) MMST_LAUNCH((dec_head_kernel<true, false>), dim3(a.B), dim3(NTHR), 0, stream, a);
   else MMST_LAUNCH((dec_head_kernel<false, true>), dim3(a.B), dim3(NTHR), 0, stream, a);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int launch_dec_bwd_mid(const DecFusedBwd& a, hipStream_t stream) {
+  if (a.B < 1 || a.T < 1 || a.T > TM || !a.ws) return MMST_ERR_ARG;
+  if (a.up_dqkv) MMST_LAUNCH((dec_bwd_mid_kernel<true>), dim3(a.B * DEC_FFN_PARTS), dim3(NTHR), 0, stream, a);
+  else MMST_LAUNCH((dec_bwd_mid_kernel<false>), dim3(a.B * DEC_FFN_PARTS), dim3(NTHR), 0, stream, a);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+int launch_dec_bwd_ln(const DecFusedLn& a, hipStream_t stream) {
+  if (a.B < 1 || a.T < 1 || a.T > TM) return MMST_ERR_ARG;
+  if (a.ws) MMST_LAUNCH((dec_bwd_ln_kernel<true>), dim3(a.B), dim3(NTHR), 0, stream, a);
+  else MMST_LAUNCH((dec_bwd_ln_kernel<false>), dim3(a.B), dim3(NTHR), 0, stream, a);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

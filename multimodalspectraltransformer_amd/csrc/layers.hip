@@ -372,6 +372,23 @@ hipEvent_t ring_event() {
   next[dev] = (next[dev] + 1) % RING;
   return ev;
 }
+// One stream of the library's own per device, created on first use: the decoder's backward keeps three chains busy
+// (activation gradients, the memory's dK / dV passes, parameter gradients) while most CUs idle.
+hipStream_t third_stream() {
+  constexpr int MAX_DEV = 16;
+  static hipStream_t streams[MAX_DEV];
+  static bool made[MAX_DEV];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!made[dev]) {
+    if (hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    made[dev] = true;
+  }
+  return streams[dev];
+}
+
 // `to` (if not null) waits for everything enqueued on `from` so far (a marker on `from`); the event is handed back
 // on request.
 int stream_fork(hipStream_t from, hipStream_t to, hipEvent_t* recorded = nullptr) {
@@ -880,6 +897,145 @@ int mmst_decoder_layer_bwd_weights(const mmst_dec_grads* g, const mmst_dec_acts*
   // 16: 8.55).  Environment: MMST_DEC_WGRAD_BLOCKS.
   static const int target = [] { const char* e = getenv("MMST_DEC_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 80; }();
   return launch_wgrads(probs, 7, (hipStream_t)stream_, 20000, target);
+}
+
+// ---- the whole decoder backward on two streams, layers nl - 1 .. 0 (w[l]->dz3 / dzd3 of the top layer given, w[l]->dx
+// of every other layer = w[l - 1]->dz3, w[l]->prev_seed = seeds[l - 1]).  Same results as nl calls of
+// mmst_decoder_layer_bwd_streams from the top layer down with join_dmem set for layer 0.  Short target sequences
+// (T <= 64, causal, fragment-major transposed weight images present): the activation gradients of a layer take five
+// launches instead of nine (dec_fused.hip): feed-forward backward per hidden quarter with the LayerNorm-3 backward of
+// the layer's incoming gradient in front, norm2 backward + cross out_proj backward, cross-attention dQ, norm1 backward
+// + self out_proj backward, self-attention backward ----
+int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, const mmst_dec_grads* const* g,
+                                   const mmst_dec_acts* const* a, const mmst_dec_bwd* const* w, int nhead, float drop_p,
+                                   const uint32_t* seeds, void* stream_, void* wstream_) {
+  if (nl < 1 || nl > MMST_MAX_LAYERS || !p || !g || !a || !w || !seeds || nhead != 16 || !wstream_ || stream_ == wstream_)
+    return MMST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_, wst = (hipStream_t)wstream_;
+  const bool dr = drop_p > 0.f;
+  bool fused = dec_fused_enabled();
+  for (int l = 0; l < nl; ++l) {
+    if (!p[l] || !g[l] || !a[l] || !w[l]) return MMST_ERR_ARG;
+    const mmst_dec_acts& A = *a[l];
+    if (A.T < 1 || A.T > 64 || A.no_causal || A.B != a[0]->B || A.T != a[0]->T || A.L != a[0]->L || !A.ffn_ws) fused = false;
+    if (!p[l]->ft_qkv || !p[l]->ft_o || !p[l]->ft_cqkv || !p[l]->ft_co || !p[l]->ft_1 || !p[l]->ft_2 || !w[l]->delta2)
+      fused = false;
+    if (l > 0 && (w[l]->dx != w[l - 1]->dz3 || w[l]->prev_z3 != a[l - 1]->z3 || (dr && w[l]->dxd != w[l - 1]->dzd3)))
+      fused = false;
+    if (l > 0 && w[l]->prev_seed != seeds[l - 1]) fused = false;
+  }
+  if (!fused) {
+    for (int l = nl - 1; l >= 0; --l)
+      RUN(mmst_decoder_layer_bwd_streams(p[l], g[l], a[l], w[l], nhead, drop_p, seeds[l], l == 0 ? 1 : 0, stream_, wstream_));
+    return MMST_OK;
+  }
+  const int B = a[0]->B, T = a[0]->T, Lm = a[0]->L, M = B * T, ML = B * Lm, hd = D / nhead;
+  hipEvent_t dmem_done = nullptr;
+  hipEvent_t layer_done[MMST_MAX_LAYERS];
+  static const bool use_third = [] { const char* e = getenv("MMST_DEC_THIRD_STREAM"); return e ? atoi(e) != 0 : true; }();
+  hipStream_t xst = use_third ? third_stream() : nullptr;
+  for (int l = nl - 1; l >= 0; --l) {
+    const mmst_dec_params& P = *p[l];
+    const mmst_dec_grads& G = *g[l];
+    const mmst_dec_acts& A = *a[l];
+    const mmst_dec_bwd& W = *w[l];
+    {   // feed-forward backward; below the top layer it first turns the layer above's dqkv into this layer's dz3 / dzd3
+      DecFusedBwd m;
+      memset(&m, 0, sizeof(m));
+      m.p = P; m.g = G; m.a = A; m.w = W; m.seed = seeds[l];
+      if (l + 1 < nl) { m.up_dqkv = w[l + 1]->dqkv; m.up_dz1 = w[l + 1]->dz1; m.up_ft_qkv = p[l + 1]->ft_qkv; }
+      m.B = B; m.T = T; m.drop_p = drop_p; m.ws = A.ffn_ws;
+      RUN(launch_dec_bwd_mid(m, st));
+    }
+    {   // norm2 backward, cross-attention out_proj backward
+      DecFusedLn k;
+      memset(&k, 0, sizeof(k));
+      k.ws = A.ffn_ws; k.res = W.dz3; k.z = A.z2; k.stats = A.st2; k.gamma = P.g2; k.dgamma = G.g2; k.dbeta = G.be2;
+      k.dz = W.dz2; k.dzd = W.dzd2; k.ft_out = P.ft_co; k.out = W.da2; k.seed = seeds[l] + 3;
+      k.B = B; k.T = T; k.drop_p = drop_p;
+      RUN(launch_dec_bwd_ln(k, st));
+    }
+    AttnBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.n = 1; ab.hd = hd; ab.causal = 0; ab.drop_p = drop_p;
+    {
+      AttnProb& q = ab.p[0];
+      const bf16* kv = (const bf16*)A.kvc;
+      bf16* dkv = (bf16*)W.dkvc;
+      q.Q = (const bf16*)A.qc; q.ldq = D; q.K = kv; q.V = kv + D; q.ldk = q.ldv = 2 * D;
+      q.kbias = A.mem_bias; q.O = (bf16*)A.attn2; q.ldo = D; q.lse = A.lse2;
+      q.dO = (const bf16*)W.da2; q.lddo = D; q.delta = W.delta2;
+      q.dQ = (bf16*)W.dqc; q.lddq = D; q.dK = dkv; q.dV = dkv + D; q.lddk = q.lddv = 2 * D;
+      q.B = B; q.H = nhead; q.Tq = T; q.Sk = Lm; q.seed = seeds[l] + 2;
+    }
+    hipEvent_t q_done = arm_completion_event();   // of the dQ kernel: it also leaves delta2
+    hipEvent_t kv_done = nullptr;
+    RUN(launch_attn_bwd_q(ab, st));
+    {   // the memory's dK / dV and their projection into dmem feed the encoder only: second stream
+      RUN(wait_for(wst, q_done));
+      if (xst) kv_done = arm_completion_event();   // the parameter gradients read dkvc
+      RUN(launch_attn_bwd_kv(ab, wst));
+      GemmBatch gk;
+      gk.n = 1;
+      GemmProb q = dgrad(W.dkvc, ML, 2 * D, (const bf16*)P.w_cqkv + D * D, D, W.dmem);
+      if (W.dmem_accumulate) { q.R = (const bf16*)W.dmem; q.ldr = D; }
+      gk.p[0] = q;
+      RUN(launch_gemm(gk, EPI_BIAS, false, true, wst));
+      if (l == 0) RUN(stream_fork(wst, nullptr, &dmem_done));
+    }
+    {   // norm1 backward, self-attention out_proj backward
+      DecFusedLn k;
+      memset(&k, 0, sizeof(k));
+      k.in = W.dqc; k.ft_in = P.ft_cqkv; k.res = W.dz2; k.z = A.z1; k.stats = A.st1; k.gamma = P.g1; k.dgamma = G.g1;
+      k.dbeta = G.be1; k.dz = W.dz1; k.dzd = W.dzd1; k.ft_out = P.ft_o; k.out = W.da; k.seed = seeds[l] + 1;
+      k.B = B; k.T = T; k.drop_p = drop_p;
+      RUN(launch_dec_bwd_ln(k, st));
+    }
+    ab.causal = 1;
+    {
+      AttnProb& q = ab.p[0];
+      memset(&q, 0, sizeof(q));
+      const bf16* qkv = (const bf16*)A.qkv;
+      bf16* dqkv = (bf16*)W.dqkv;
+      q.Q = qkv; q.K = qkv + D; q.V = qkv + 2 * D; q.ldq = q.ldk = q.ldv = 3 * D;
+      q.O = (bf16*)A.attn1; q.ldo = D; q.lse = A.lse1;
+      q.dO = (const bf16*)W.da; q.lddo = D; q.delta = W.delta;
+      q.dQ = dqkv; q.dK = dqkv + D; q.dV = dqkv + 2 * D; q.lddq = q.lddk = q.lddv = 3 * D;
+      q.B = B; q.H = nhead; q.Tq = T; q.Sk = T; q.seed = seeds[l] + 0;
+    }
+    hipEvent_t done = nullptr;
+    if (l > 0) done = arm_completion_event();
+    RUN(launch_attn_bwd(ab, st));
+    if (l == 0) {   // the bottom layer: gradient at the target embedding
+      GemmBatch gb;
+      gb.n = 1;
+      GemmProb q = dgrad(W.dqkv, M, 3 * D, P.w_qkv, D, W.dx);
+      q.R = (const bf16*)W.dz1; q.ldr = D;
+      gb.p[0] = q;
+      done = arm_completion_event();
+      RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+    }
+    // The layer's parameter gradients: not on wstream, where they would sit in front of the next layer's dK / dV pass
+    // (the chain of those passes, each waiting for its layer's dQ kernel, is what the encoder's backward waits for),
+    // but on a third stream, beside both chains; wstream takes them in at the end.
+    if (xst) {
+      RUN(wait_for(xst, done));
+      RUN(wait_for(xst, kv_done));
+      RUN(mmst_decoder_layer_bwd_weights(g[l], a[l], w[l], drop_p, xst));
+    } else {
+      layer_done[l] = done;
+    }
+  }
+  if (xst) {
+    RUN(stream_fork(xst, wst));
+  } else {
+    for (int l = nl - 1; l >= 0; --l) {
+      RUN(wait_for(wst, layer_done[l]));
+      RUN(mmst_decoder_layer_bwd_weights(g[l], a[l], w[l], drop_p, wstream_));
+    }
+  }
+  if (dmem_done && hipStreamWaitEvent(st, dmem_done, 0) != hipSuccess) return MMST_ERR_LAUNCH;
+  return MMST_OK;
 }
 
 int mmst_decoder_layer_bwd(const mmst_dec_params* p, const mmst_dec_grads* g, const mmst_dec_acts* a,

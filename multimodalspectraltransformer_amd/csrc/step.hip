@@ -144,14 +144,23 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
     g.ksplit = M / 256 < 1 ? 1 : (M / 256 > 16 ? 16 : M / 256);
     RUN(one_gemm(g, EPI_ATOMIC, true, true, wst));
   }
-  for (int l = ndl - 1; l >= 0; --l) {
-    mmst_dec_acts a = *pl->dec_a[l];
-    a.T = T; a.kv_ready = 0; a.no_causal = 0;
-    mmst_dec_bwd w = *pl->dec_w[l];
-    w.dzd3 = dr ? pl->dec_dzd[l] : w.dz3;
-    w.prev_seed = l > 0 ? layer_seed(ar->step_seed, UID_DEC + l - 1) : 0;
-    RUN(mmst_decoder_layer_bwd_streams(pl->dec_p[l], pl->dec_g[l], &a, &w, 16, dp, layer_seed(ar->step_seed, UID_DEC + l),
-                                       l == 0 ? 1 : 0, st, wst));
+  {
+    mmst_dec_acts acts[MMST_MAX_LAYERS];
+    mmst_dec_bwd bw[MMST_MAX_LAYERS];
+    const mmst_dec_acts* ap[MMST_MAX_LAYERS];
+    const mmst_dec_bwd* wp[MMST_MAX_LAYERS];
+    uint32_t seeds[MMST_MAX_LAYERS];
+    for (int l = 0; l < ndl; ++l) {
+      acts[l] = *pl->dec_a[l];
+      acts[l].T = T; acts[l].kv_ready = 0; acts[l].no_causal = 0;
+      bw[l] = *pl->dec_w[l];
+      bw[l].dzd3 = dr ? pl->dec_dzd[l] : bw[l].dz3;
+      seeds[l] = layer_seed(ar->step_seed, UID_DEC + l);
+      bw[l].prev_seed = l > 0 ? layer_seed(ar->step_seed, UID_DEC + l - 1) : 0;
+      ap[l] = &acts[l];
+      wp[l] = &bw[l];
+    }
+    RUN(mmst_decoder_stack_bwd_streams(ndl, pl->dec_p, pl->dec_g, ap, wp, 16, dp, seeds, st, wst));
   }
   // the target-embedding gradients feed parameters only: second stream
   RUN(mmst_stream_fork(st, wst));

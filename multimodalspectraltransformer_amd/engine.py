@@ -958,16 +958,20 @@ class Engine:
                 ops.gemm([dict(P=_P(pl.dlogits), Q=_P(last["y"]), C=ar.g32("fc_out.weight"), dbias=ar.g32("fc_out.bias"),
                                ldp=VPAD, ldq=D, ldc=D, Pn=VPAD, Qn=D, K=M, ksplit=max(1, min(16, M // 256)))],
                          L.EPI_ATOMIC, pt=True, qt=True)
-            for l in reversed(range(ndl)):
+            for l in range(ndl):
                 w = pl.dec_w[l]
                 w.dzd3 = pl.dec_dzd[l][1] if p_drop > 0 else pl.dec_dzd[l][0]
                 w.prev_seed = self.layer_seed(64 + l - 1) if l > 0 else 0
+            if self.decoder_kv_on_wstream:
+                arr = lambda xs: (C.c_void_p * ndl)(*[C.addressof(x) for x in xs])  # noqa: E731
+                seeds = (C.c_uint32 * ndl)(*[self.layer_seed(64 + l) for l in range(ndl)])
+                L.check(lib.mmst_decoder_stack_bwd_streams(ndl, arr(pl.dec_p), arr(pl.dec_g), arr(pl.dec_a), arr(pl.dec_w),
+                                                           16, C.c_float(p_drop), seeds, st, wst),
+                        "mmst_decoder_stack_bwd_streams")
+            for l in reversed(range(ndl)):
+                w = pl.dec_w[l]
                 if self.decoder_kv_on_wstream:
-                    L.check(lib.mmst_decoder_layer_bwd_streams(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]),
-                                                               C.byref(pl.dec_a[l]), C.byref(w), 16, C.c_float(p_drop),
-                                                               C.c_uint32(self.layer_seed(64 + l)), 1 if l == 0 else 0,
-                                                               st, wst), "mmst_decoder_layer_bwd_streams")
-                    continue
+                    break
                 L.check(lib.mmst_decoder_layer_bwd_data(C.byref(pl.dec_p[l]), C.byref(pl.dec_g[l]), C.byref(pl.dec_a[l]),
                                                         C.byref(w), 16, C.c_float(p_drop),
                                                         C.c_uint32(self.layer_seed(64 + l)), st),
