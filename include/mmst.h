@@ -214,13 +214,13 @@ typedef struct {
                                   j < pos of sequence b from the cache of sequence (b / kv_group) * kv_group + hist[b][j],
                                   so a beam that descends from another beam's prefix needs no copy of that prefix's
                                   cache rows; position pos is always the sequence's own new row */
-  void* ffn_ws;                /* optional workspace of MMST_DEC_STACK_WS_BYTES(B) bytes, 256-byte aligned: with it (and at
-                                  least 256 sequences) the feed-forward block of every layer runs as a launch of its own
+  void* ffn_ws;                /* optional workspace of MMST_DEC_STACK_WS_BYTES(B) bytes, 256-byte aligned: with it the
+                                  feed-forward block of every layer runs as a launch of its own
                                   over all sequences, which reads its weights once per call instead of once per
                                   workgroup; same arithmetic, the hidden dimension summed in 16 slices */
 } mmst_dec_stack_step;
 /* Process-wide: the least number of sequences (B) from which a call with ffn_ws takes the split form; 0 = never,
- * negative = the default (256, or what the environment variable MMST_DECODE_SPLIT_FFN says).  No counterpart in the
+ * negative = the default (1, or what the environment variable MMST_DECODE_SPLIT_FFN says).  No counterpart in the
  * reference: a tuning switch, used by the tests to run both forms on small batches. */
 int mmst_decoder_stack_config(int split_min_sequences);
 #define MMST_DEC_STACK_WS_BYTES(B) ((((size_t)(B) * 128 * 2 + 255) & ~(size_t)255) + (size_t)16 * (B) * 128 * 4)

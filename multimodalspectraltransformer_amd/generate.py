@@ -133,7 +133,7 @@ def _cross_kv(model, pl):
 
 
 def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None,
-                        keep_logits=None):
+                        keep_logits=None, kv_ready=False):
     """Decode loop with cached keys/values: per token one new row through the decoder.
 
     With MMST_DECODE_GRAPH=1 greedy decoding replays one hipGraph per target position (captured on first use, kept
@@ -156,7 +156,8 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
     tok[0].fill_(sos)
     was_training = model.training
     model.eval()
-    _cross_kv(model, pl)
+    if not kv_ready:   # kv_ready: the plan's last forward pass has projected this memory with the current weights
+        _cross_kv(model, pl)
     emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
     use_graph = (not sample) and os.environ.get("MMST_DECODE_GRAPH", "0") == "1"
 
@@ -223,7 +224,7 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
 
 
 def _decode_plan(model, pl, max_len, temperature, sos, early_stop, sample=False, generator=None, cached=None,
-                 keep_logits=None):
+                 keep_logits=None, kv_ready=False):
     """Shared loop on an encoded plan.  Returns tokens (steps+1, B) incl. <SOS> and probs (steps, B).
     keep_logits: optional fp32 [max_len][B][64] buffer that receives every position's logits (cached path only)."""
     if cached is None:
@@ -231,7 +232,8 @@ def _decode_plan(model, pl, max_len, temperature, sos, early_stop, sample=False,
     if keep_logits is not None and not cached:
         raise L.MMSTError("keep_logits needs the cached decode")
     if cached:
-        return _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample, generator, keep_logits)
+        return _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample, generator, keep_logits,
+                                   kv_ready)
     eng = model._engine
     B = pl.B
     lib, st = L.lib(), L.stream_ptr
@@ -325,7 +327,7 @@ def predict_prop_correct_max_sequence(model, stoi, memory, src_padding_mask, trg
     return real.t().contiguous(), corr, nxt.t().contiguous(), max_prob, multinom
 
 
-def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=None, generator=None):
+def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=None, generator=None, kv_ready=False):
     """In-training generation, TransformerMultiGPU._generate_sequences (models_MMT_v15_4.py:1222-1297), on an encoded
     plan: max_len decode steps without early stop; returns the reference's (token tensor incl. <SOS>, SMILES list,
     list of per-molecule confidence tensors).  config.sampling_method:
@@ -337,6 +339,8 @@ def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=Non
                     MULTINOMIAL confidences are the ones cut to the greedy strings' lengths (:1294); combine_gen_sims
                     then keeps the greedy result for every molecule (its except-branch needs Chem.MolFromSmiles to
                     raise, which it does not for strings: it returns None).
+    kv_ready: the plan's last forward pass ran with the current weights, so the decoder layers' projections of the
+    memory (keys/values) are already in the plan and are not recomputed.
     """
     sos = stoi["<SOS>"] if stoi else 3
     max_len = int(max_len or config.max_len)
@@ -346,7 +350,7 @@ def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=Non
     V = model.out_size
     if method == "multinomial":
         keep = torch.empty(1, pl.B, VPAD, dtype=torch.float32, device=model._engine.device)
-        _decode_plan(model, pl, 1, temperature, sos, early_stop=False, cached=True, keep_logits=keep)
+        _decode_plan(model, pl, 1, temperature, sos, early_stop=False, cached=True, keep_logits=keep, kv_ready=kv_ready)
         p0 = torch.softmax(keep[0, :, :V] / temperature, dim=1)
         nxt = torch.multinomial(p0, max_len, replacement=True, generator=generator)        # (B, max_len)
         toks = torch.cat((torch.full((1, pl.B), sos, dtype=torch.long, device=nxt.device), nxt.t()), dim=0)
@@ -356,7 +360,8 @@ def generate_sequences(model, pl, config, stoi, itos, temperature=1, max_len=Non
         if method == "mix":
             keep = torch.empty(max_len, pl.B, VPAD, dtype=torch.float32, device=model._engine.device)
         toks, probs = _decode_plan(model, pl, max_len, temperature, sos, early_stop=False,
-                                   cached=True if method == "mix" else None, keep_logits=keep)
+                                   cached=True if method == "mix" or kv_ready else None, keep_logits=keep,
+                                   kv_ready=kv_ready)
         if method == "mix":
             p = torch.softmax(keep[:, :, :V] / temperature, dim=2)
             nxt = torch.multinomial(p.reshape(-1, V), 1, generator=generator)

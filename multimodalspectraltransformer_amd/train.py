@@ -263,7 +263,10 @@ class TransformerMultiGPU:
             # MMST_REDUCE_PATH=1 takes the several-rank host path (segment callbacks, separate optimizer launch) with
             # one rank too, to time it on one GPU
             ddp_path = self.world > 1 or os.environ.get("MMST_REDUCE_PATH") == "1"
-            if not ddp_path:
+            # in-training generation decodes with the weights the forward pass used (the reference calls it between
+            # forward and loss, models_MMT_v15_4.py:1064-1077): the optimizer runs behind it, as a launch of its own
+            gen = bool(getattr(self.config, "gen_SMI_sequence", False))
+            if not ddp_path and not gen:
                 opt.step_count += 1
                 ar.weights_serial += 1
                 adam = (opt.step_count, opt.lr, opt.betas, opt.eps, opt.wd)
@@ -275,23 +278,36 @@ class TransformerMultiGPU:
                     self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),))
             loss = eng.train_step(pl, x, train=True, zero_grads=not ar.grads_zeroed, adam=adam, on_segment=cb)
             model._last_plan = pl
-            if ddp_path:
+            if gen:
+                gen_out = self._generate_before_optimizer(pl)
+            if ddp_path or gen:
                 scale = self.reducer.finish()
                 self.optimizer.step(self.config.training_mode, grad_scale=scale)
         else:
             ar.G.zero_()
             loss = model.loss_and_backward(
                 x, on_segment=lambda name: self.reducer.on_segment(name, also=(getattr(eng, "wstream", None),)))
+            if getattr(self.config, "gen_SMI_sequence", False):
+                gen_out = self._generate_before_optimizer(model._last_plan)
             scale = self.reducer.finish()
             self.optimizer.step(self.config.training_mode, grad_scale=scale)
         out = {'loss': loss.clone()}   # the plan's loss slot is rewritten by the next step
         self.last_train_loss = out['loss']
         self.global_step += 1
         if getattr(self.config, "gen_SMI_sequence", False):
-            from .generate import generate_sequences
-            pl = model._last_plan
-            out['gen'] = generate_sequences(model, pl, self.config, self.stoi, self.itos, temperature=1)
-            model.train()
+            out['gen'] = gen_out
+        return out
+
+    def _generate_before_optimizer(self, pl):
+        """In-training generation on the plan of the step that has just been enqueued, BEFORE its optimizer: the
+        reference generates between the forward pass and the loss (models_MMT_v15_4.py:1064-1077), i.e. with the weights
+        the forward pass used, on that pass's train-mode memory; the decoder layers' projections of that memory are
+        still in the plan.  (Running the decode loop on a stream of its own beside the backward pass gains nothing: a
+        workgroup of the token step is 1024 threads and needs a whole idle compute unit, which the backward kernels
+        never leave; measured, the first token launch started when backward ended.)"""
+        from .generate import generate_sequences
+        out = generate_sequences(self.model, pl, self.config, self.stoi, self.itos, temperature=1, kv_ready=True)
+        self.model.train()
         return out
 
     def validation_step(self, x, batch_idx=0):

@@ -83,6 +83,62 @@ def test_generate_sequences_multinomial_and_mix():
     assert np.median([float(c.mean()) for c in conf2 if len(c)]) > 0.8
 
 
+def test_training_step_generates_with_the_weights_of_its_forward_pass(monkeypatch, tmp_path):
+    """The reference generates between the forward pass and the loss (models_MMT_v15_4.py:1064-1077): with the weights
+    the step STARTED with, on the train-mode memory of that step.  The step's generation (optimizer behind it) must
+    return what _generate_sequences returns for a twin of the model that never takes the optimizer step, on both step
+    paths (one call into the library / launch by launch); and the weights after the step are those of the step without
+    generation."""
+    name, mode = GREEDY[0]
+    g = load_golden(name)
+    stoi = json.load(open(os.path.join(GOLDEN, "stoi.json")))
+    itos = json.load(open(os.path.join(GOLDEN, "itos.json")))
+
+    def wrapper(gen_on):
+        model, config, cfg, sd, batch, db = build(g, mode, gain=float(g["gain"]))
+        config.model_save_dir = str(tmp_path)
+        tm = TransformerMultiGPU.__new__(TransformerMultiGPU)
+        tm.__dict__.update(config=config, model=model, lr=1e-3, stoi=stoi, itos=itos, optimizer=None, scheduler=None,
+                           reducer=None, world=1, global_step=0, current_epoch=0, last_train_loss=None)
+        config.gen_SMI_sequence, config.sampling_method = gen_on, "greedy"
+        model._engine.step_seed = 4242
+        return tm, model, config, db
+
+    outs = []
+    for c_step in ("1", "0"):
+        monkeypatch.setenv("MMST_C_STEP", c_step)
+        tm, model, config, db = wrapper(True)
+        out = tm.training_step(dict(db), 0)
+        toks, smiles, conf = out["gen"]
+        outs.append((toks.cpu().clone(), smiles, float(out["loss"]), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+        assert model.training
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    # the twin: same weights, same dropout stream, forward in train mode only, then the reference-signature generation
+    tm, model, config, db = wrapper(False)
+    eng = model._engine
+    model.train()
+    eng.step_seed = (4242 * 1664525 + 1013904223) & 0xFFFFFFFF
+    db["src_HSQC_"], db["src_COSY_"] = db["src_HSQC"], db["src_COSY"]
+    trg = db["trg_enc_SMI"].t()
+    with torch.no_grad():
+        logits, fp, memory, mask = call(model, mode, db, trg[:-1, :])
+    config.sampling_method = "greedy"
+    toks_t, smiles_t, conf_t = tm._generate_sequences(model, config, memory, mask, config.max_len, 1, stoi, itos)
+    same = float((toks_t.cpu() == outs[0][0]).float().mean())
+    assert same == 1.0, same
+    assert smiles_t == outs[0][1]
+    # ... and the optimizer step itself is the one of a step without generation
+    monkeypatch.setenv("MMST_C_STEP", "1")
+    tm, model, config, db = wrapper(False)
+    out = tm.training_step(dict(db), 0)
+    assert abs(float(out["loss"]) - outs[0][2]) < 1e-6
+    post = model.state_dict()
+    for k in ("decoder.layers.1.linear1.weight", "encoder_cross.layers.0.self_attn.in_proj_weight", "fc_out.weight",
+              "embed_trg.weight"):
+        assert float((post[k].cpu() - outs[0][3][k]).abs().max()) < 1e-6, k
+        assert float((post[k].cpu() - outs[1][3][k]).abs().max()) < 2e-4, k
+
+
 def test_validation_step_loss_vs_reference():
     g = load_golden("fwd_c2_L2")
     model, config, cfg, sd, batch, db = build(g, MODE)
