@@ -201,7 +201,8 @@ typedef struct {
   const float* mem_bias;       /* [B / kv_group][L] additive key bias, or NULL */
   const void* w_out; const float* b_out;  /* optional vocabulary projection, bf16 [n_out][128] / fp32 [n_out] */
   float* logits; int ld_logits; int n_out; /* out: logits[b*ld_logits + 0..n_out) fp32, n_out <= 64 */
-  int64_t* next_tok; float* next_prob;    /* optional [B]: greedy choice among logits[0..V) and its probability */
+  int64_t* next_tok; float* next_prob;    /* optional [B]: choice among logits[0..V) and its probability: greedy, or
+                                             (sample != 0) a draw as mmst_sample_select makes it with counter = pos */
   float temperature; int V;
   int B, pos, cap, L;
   int kv_group;                /* >= 1: sequences b*kv_group .. (b+1)*kv_group-1 share row block b of kvc and mem_bias
@@ -218,6 +219,8 @@ typedef struct {
                                   feed-forward block of every layer runs as a launch of its own
                                   over all sequences, which reads its weights once per call instead of once per
                                   workgroup; same arithmetic, the hidden dimension summed in 16 slices */
+  int sample; uint32_t sample_seed;   /* sample != 0: next_tok is drawn from softmax(logits / temperature) instead of
+                                         being its argmax (seed, counter = pos, row = sequence) */
 } mmst_dec_stack_step;
 /* Process-wide: the least number of sequences (B) from which a call with ffn_ws takes the split form; 0 = never,
  * negative = the default (1, or what the environment variable MMST_DECODE_SPLIT_FFN says).  No counterpart in the
@@ -362,6 +365,14 @@ int mmst_seq_mean_bwd_add(const float* dmean, void* dmem, int B, int L, void* st
  * position: validate_generate_MMT_v15_4.py:754-762 / models_MMT_v15_4.py:1246-1256.  logits [B][T][ldl]. */
 int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float temperature, int64_t* next_tok,
                        float* next_prob, void* stream);
+/* The multinomial decode loops' selection, torch.multinomial(softmax(logits / temperature), 1) and the gather of its
+ * probability (validate_generate_MMT_v15_4.py:841-880, mmt_result_test_functions_15_4.py:791-829,
+ * models_MMT_v15_4.py:1258-1264), without a generator state on the device: row b draws the inverse CDF at a uniform
+ * number that is a pure function of (seed, counter, b), so a caller that passes the target position as the counter
+ * gets independent draws per position and row and the same tokens again for the same seed.  Same distribution as
+ * torch's, not the same stream of numbers.  Never returns an index of probability zero. */
+int mmst_sample_select(const float* logits, int ldl, int V, int B, int T, float temperature, uint32_t seed,
+                       uint32_t counter, int64_t* next_tok, float* next_prob, void* stream);
 
 /* torch.optim.AdamW step (:1213-1214) on flat fp32 buffers + refresh of the bf16 weight copy. */
 int mmst_adamw(float* param, const float* grad, float* m, float* v, void* param_bf16, long n, float lr, float beta1,

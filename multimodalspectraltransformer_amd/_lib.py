@@ -176,7 +176,7 @@ class DecStackStep(C.Structure):
         "next_tok", "next_prob") + [("temperature", C.c_float), ("V", C.c_int),
                                     ("B", C.c_int), ("pos", C.c_int), ("cap", C.c_int), ("L", C.c_int),
                                     ("kv_group", C.c_int), ("rows_per_group", C.c_int), ("hist", C.c_void_p),
-                                    ("ffn_ws", C.c_void_p)]
+                                    ("ffn_ws", C.c_void_p), ("sample", C.c_int), ("sample_seed", C.c_uint32)]
 
 
 class DecBwd(C.Structure):

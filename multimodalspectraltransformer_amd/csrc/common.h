@@ -137,3 +137,35 @@ __device__ __forceinline__ float xor16_max(float v) { float a = v, b = v; lanes_
 // whole wave, no trip through the LDS crossbar
 __device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
+
+// Token choice of one decode step by one wave: lane i < V holds x = logit_i / temperature, the other lanes -infinity.
+// Greedy (sample == false): the first index of the maximum (torch.argmax's tie rule).  Sampling: the inverse CDF of
+// softmax(x) at a uniform number that is a pure function of (seed, counter, row) -- 24 bits of two rounds of the
+// counter hash -- so a draw can be repeated, and needs no generator state on the device: the first index whose
+// cumulative probability exceeds u, never an index of probability zero.  Returns the index on every lane; *prob =
+// its softmax probability.
+__device__ __forceinline__ int wave_select_token(float x, int V, bool sample, uint32_t seed, uint32_t counter,
+                                                 uint32_t row, float* prob) {
+  const int lane = threadIdx.x & 63;
+  const float mx = wave_max(x);
+  const float e = lane < V ? __expf(x - mx) : 0.f;
+  const float se = wave_sum(e);
+  int arg;
+  if (!sample) {
+    arg = __ffsll((long long)__ballot(x == mx)) - 1;
+  } else {
+    float cum = e;   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float t = __shfl_up(cum, d);
+      if (lane >= d) cum += t;
+    }
+    const uint32_t h = mix32(mix32(seed + counter * 0x9E3779B9U) + row * 0x85EBCA6BU);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f) * se;   // [0, se)
+    const unsigned long long hit = __ballot(cum > u && e > 0.f);
+    const unsigned long long any = __ballot(e > 0.f);
+    arg = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);   // rounding at the top end: the last index
+  }
+  *prob = __shfl(e, arg) / se;
+  return arg;
+}

@@ -31,6 +31,9 @@ namespace {
 #ifndef MMST_DECODE_SHARED_CROSS
 #define MMST_DECODE_SHARED_CROSS 1
 #endif
+#ifndef MMST_DEC_HEAD_MINOR_MAXR   // measurement builds: the lane layout of the attention passes, see head_minor()
+#define MMST_DEC_HEAD_MINOR_MAXR 1
+#endif
 constexpr int D = MMST_D, FF = MMST_FF, NT = 1024, NWAVE = NT / 64, NH = 16, HD = 8;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -287,30 +290,49 @@ __device__ __forceinline__ void layernorm_rows(Smem<R>& sm, float z, const float
   lds_barrier();
 }
 
+// Lane layout of the attention passes: a lane serves one head (8 of a row's 128 columns, 16 bytes) of one of the four
+// keys a wave covers per step.  Head-minor (lane = 16 key slot + head): the 16 lanes of a key slot read that key's
+// 256-byte row, so every four neighbouring lanes fetch 64 contiguous bytes; head-major (lane = 4 head + key slot): the
+// four lanes of a quad touch four rows, and the address unit takes a cycle per row a quad touches, but the merge of the
+// four key slots is free (quad permutes).  One sequence per workgroup is bound by the pass over the memory keys/values
+// and takes the first; measured with 3 sequences per workgroup (beam search) the second is ahead.
+template <int R> __device__ __forceinline__ constexpr bool head_minor() { return R <= MMST_DEC_HEAD_MINOR_MAXR; }
+template <int R> __device__ __forceinline__ int head_of(int lane) { return head_minor<R>() ? (lane & 15) : (lane >> 2); }
+template <int R> __device__ __forceinline__ int key_slot_of(int lane) { return head_minor<R>() ? (lane >> 4) : (lane & 3); }
+
 // merge of the per-lane online-softmax states (m, l, acc[8]) of Q query rows at once: the 4 key slots of a wave (the
 // lanes of a quad), then the waves through LDS (two barriers for all the rows); results -> out + r*D (bf16-rounded)
 template <int R, int Q>
 __device__ __forceinline__ void merge_softmax_all(Smem<R>& sm, float (&m)[Q], float (&l)[Q], float (&acc)[Q][HD], bf16* out,
                                                   int tid) {
   static_assert(Q <= R, "one partial array per sequence of the workgroup");
-  // lane = 4 head + key slot: the four key slots of a head are the lanes of a quad, merged by quad permutes inside the
-  // add / max instructions (no trip through the LDS crossbar)
-  const int lane = tid & 63, wave = tid >> 6, hh = lane >> 2;
+  // the four key slots of a head are merged without a trip through the LDS crossbar: 16 and 32 lanes apart, by the two
+  // lane-swap instructions; or the lanes of a quad, by quad permutes inside the add / max instructions
+  const int lane = tid & 63, wave = tid >> 6, hh = head_of<R>(lane);
 #pragma unroll
   for (int r = 0; r < Q; ++r) {
-    float M = fmaxf(m[r], dpp_f32<0xB1>(m[r]));
-    M = fmaxf(M, dpp_f32<0x4E>(M));
-    const float f = __builtin_amdgcn_exp2f(m[r] - M);
-    float lr = l[r] * f;
-    lr += dpp_f32<0xB1>(lr);
-    lr += dpp_f32<0x4E>(lr);
+    float M, lr;
+    if constexpr (head_minor<R>()) {
+      M = xor32_max(xor16_max(m[r]));
+      const float f = __builtin_amdgcn_exp2f(m[r] - M);
+      lr = xor32_sum(xor16_sum(l[r] * f));
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      acc[r][d] *= f;
-      acc[r][d] += dpp_f32<0xB1>(acc[r][d]);
-      acc[r][d] += dpp_f32<0x4E>(acc[r][d]);
+      for (int d = 0; d < HD; ++d) acc[r][d] = xor32_sum(xor16_sum(acc[r][d] * f));
+    } else {
+      M = fmaxf(m[r], dpp_f32<0xB1>(m[r]));
+      M = fmaxf(M, dpp_f32<0x4E>(M));
+      const float f = __builtin_amdgcn_exp2f(m[r] - M);
+      lr = l[r] * f;
+      lr += dpp_f32<0xB1>(lr);
+      lr += dpp_f32<0x4E>(lr);
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        acc[r][d] *= f;
+        acc[r][d] += dpp_f32<0xB1>(acc[r][d]);
+        acc[r][d] += dpp_f32<0x4E>(acc[r][d]);
+      }
     }
-    if ((lane & 3) == 0) {
+    if (key_slot_of<R>(lane) == 0) {
       sm.part[r][wave][hh][0] = M;
       sm.part[r][wave][hh][1] = lr;
 #pragma unroll
@@ -338,8 +360,7 @@ __device__ __forceinline__ void merge_softmax_all(Smem<R>& sm, float (&m)[Q], fl
 // Attention of Q query rows (q + r*qstride, 16 heads x 8) over the SAME `nkeys` keys: K row of key j at kbase + j*ld, V
 // at vbase + j*ld (bf16, 128 wide) -- unless `slot_of` is given: then key j lives in the cache of sequence slot_of[j] of
 // the molecule, kbase + (slot_of[j]*cap + j)*ld (a beam's history points into the caches of the beams it descends
-// from).  Lane = 4 head + key slot: a wave covers 4 keys per step (each key's 256-byte row read by 16 of its lanes), the
-// workgroup 64.  If last_k != nullptr (Q == 1 only), key nkeys-1 is read from LDS instead (the row this workgroup
+// from).  A wave covers 4 keys per step, the workgroup 64 (lane layout: head_minor()).  If last_k != nullptr (Q == 1 only), key nkeys-1 is read from LDS instead (the row this workgroup
 // has just produced).  Results -> out + r*D (bf16-rounded).
 // STREAM: the keys/values are read once per launch by this workgroup only (the projected encoder memory): they are
 // loaded with the non-temporal hint, so that they do not push the decoder weights, which every workgroup of the XCD
@@ -350,7 +371,7 @@ __device__ __forceinline__ void attend_scores(const float* q, int qstride, const
                                               const int32_t* slot_of, int cap, int tid, float (&m)[Q], float (&l)[Q],
                                               float (&acc)[Q][HD]) {
   const int lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 2, slot = wave * 4 + (lane & 3);
+  const int hh = head_of<R>(lane), slot = wave * 4 + key_slot_of<R>(lane);
   const float scale2 = rsqrtf((float)HD) * LOG2E;
   bf16x2 qv[Q][4];
 #pragma unroll
@@ -424,6 +445,15 @@ __device__ __forceinline__ void attend(Smem<R>& sm, const float* q, int qstride,
   merge_softmax_all<R, Q>(sm, m, l, acc, out, tid);
 }
 
+// Timing builds (-DMMST_DEC_STAMP): the first lane of workgroup 0 of the launch of layer 2 leaves shader-clock stamps of
+// its phases behind the used part of the split step's workspace (tools/bench_gen.py allocates the room)
+#ifdef MMST_DEC_STAMP
+#define DSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && args.l_begin == 2) \
+    ((unsigned long long*)((char*)args.s.ffn_ws + MMST_DEC_STACK_WS_BYTES(args.s.B)))[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+
 // SPLIT: an instance for the launches of the split token step that stop behind norm2 (no feed-forward code in it)
 template <int R, bool SPLIT = false>
 __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) {
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   const int tid = threadIdx.x, g = blockIdx.x;
   const int b0 = g * R;               // first sequence of this workgroup
   const int pos = s.pos;
+  DSTAMP(0);
   if (args.mode & MODE_PRO) {
     // input rows = norm3(x2 + b2 + sum of the feed-forward partials) of the layer in front
     const mmst_dec_params& pp = args.p[args.l_begin - 1];
@@ -462,6 +493,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     sm.vx[r][c] = v;
   }
   lds_barrier();
+  DSTAMP(1);
   const int bm = R > 1 ? g : b0 / s.kv_group;   // row block of the encoder memory these sequences read
   const float* mbias = s.mem_bias ? s.mem_bias + (size_t)bm * s.L : nullptr;
   for (int l = args.l_begin; l < args.l_end; ++l) {
@@ -474,6 +506,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
       cache[((size_t)r * s.cap + pos) * 3 * D + n] = q;
     });
     lds_barrier();
+    DSTAMP(2);
     // 2. self-attention over positions 0..pos (every cached key is visible).  With a history table the key of position
     //    j is read from the cache of the sequence that produced it (slot hist[b][j] of this molecule); position `pos`
     //    itself is the row just computed.
@@ -482,7 +515,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
       if (R > 1 && pos + 1 <= 4 * NWAVE) {
         // at most one key per lane: the key/value rows of ALL R sequences are requested before the first one is used
         // (one round trip to the caches instead of R), the arithmetic is that of the general loop for a single key
-        const int lane = tid & 63, hh = lane >> 2, key = (tid >> 6) * 4 + (lane & 3);
+        const int lane = tid & 63, hh = head_of<R>(lane), key = (tid >> 6) * 4 + key_slot_of<R>(lane);
         const bool valid = key <= pos;
         const float scale2 = rsqrtf((float)HD) * LOG2E;
         bf16x8 kt[R], vt[R];
@@ -523,18 +556,23 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
           for (int d = 0; d < HD; ++d) aacc[r][d] = a1[0][d];
         }
       }
+      DSTAMP(3);
       merge_softmax_all<R, R>(sm, am, al, aacc, &sm.vattn[0][0], tid);
     }
+    DSTAMP(4);
     // 3. out_proj + residual + norm1
     project_k128<R, D, 1>((const bf16*)p.w_o, p.b_o, &sm.vattn[0][0], tid,
                           [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x[r][n]; });
     lds_barrier();
     float z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
+    DSTAMP(5);
     layernorm_rows<R>(sm, z, p.g1, p.be1, sm.x1, sm.vx, tid);
+    DSTAMP(6);
     // 4. cross-attention queries
     project_k128<R, D, 1>((const bf16*)p.w_cqkv, p.b_cqkv, &sm.vx[0][0], tid,
                           [&](int r, int n, float v) { sm.qc[r][n] = rbf(v); });
     lds_barrier();
+    DSTAMP(7);
     // 5. cross-attention over the projected memory: one pass over the molecule's keys/values for all R queries
     const bf16* kv = (const bf16*)s.kvc[l] + (size_t)bm * s.L * 2 * D;
 #if MMST_DEC_SKIP & 2
@@ -546,12 +584,14 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
     for (int r = 0; r < R; ++r)
       attend<R, 1>(sm, sm.qc[r], 0, kv, kv + D, 2 * D, s.L, mbias, nullptr, nullptr, nullptr, 0, sm.vattn[r], tid);
 #endif
+    DSTAMP(8);
     // 6. out_proj + residual + norm2
     project_k128<R, D, 1>((const bf16*)p.w_co, p.b_co, &sm.vattn[0][0], tid,
                           [&](int r, int n, float v) { sm.qc[r][n] = v + sm.x1[r][n]; });
     lds_barrier();
     z = tid < R * D ? sm.qc[tid >> 7][tid & (D - 1)] : 0.f;
     layernorm_rows<R>(sm, z, p.g2, p.be2, sm.x2, sm.vx, tid);
+    DSTAMP(9);
     if constexpr (SPLIT) {   // the feed-forward block of this layer is the next launch
       if (tid < R * D) ws_rows(s.ffn_ws)[(size_t)b0 * D + tid] = sm.vx[tid >> 7][tid & (D - 1)];
       return;
@@ -588,17 +628,14 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(const StackArgs args) 
   }, s.n_out);
   if (!s.next_tok) return;
   lds_barrier();
-  if (tid < 64 * R) {   // wave r: softmax(logits / temperature) of row r, first index of the maximum
+  if (tid < 64 * R) {   // wave r: softmax(logits / temperature) of row r; first index of the maximum, or a draw
     const int lane = tid & 63, r = tid >> 6;
     const float x = lane < s.V ? sm.qc[r][lane] / s.temperature : -INFINITY;
-    const float mx = wave_max(x);
-    const float e = lane < s.V ? __expf(x - mx) : 0.f;
-    const float se = wave_sum(e);
-    const unsigned long long mk = __ballot(x == mx);
-    const int arg = __ffsll((long long)mk) - 1;
-    if (lane == arg) {
+    float pr;
+    const int arg = wave_select_token(x, s.V, s.sample != 0, s.sample_seed, (uint32_t)pos, (uint32_t)(b0 + r), &pr);
+    if (lane == 0) {
       s.next_tok[b0 + r] = arg;
-      if (s.next_prob) s.next_prob[b0 + r] = e / se;
+      if (s.next_prob) s.next_prob[b0 + r] = pr;
     }
   }
 }

@@ -323,6 +323,21 @@ __global__ void greedy_select_kernel(const float* logits, int ldl, int V, int B,
   }
 }
 
+// softmax(logits / temperature) of the last position, one draw from it per row (wave_select_token)
+__global__ void sample_select_kernel(const float* logits, int ldl, int V, int B, int T, float temperature, uint32_t seed,
+                                     uint32_t counter, int64_t* next_tok, float* next_prob) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float x = lane < V ? logits[((size_t)b * T + (T - 1)) * ldl + lane] / temperature : -INFINITY;
+  float pr;
+  const int arg = wave_select_token(x, V, true, seed, counter, (uint32_t)b, &pr);
+  if (lane == 0) {
+    next_tok[b] = arg;
+    next_prob[b] = pr;
+  }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, bf16* __restrict__ pb, long n, float lr, float b1, float b2,
                              float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
@@ -558,6 +573,16 @@ int mmst_greedy_select(const float* logits, int ldl, int V, int B, int T, float 
     return MMST_ERR_ARG;
   hipLaunchKernelGGL(greedy_select_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, B, T,
                      temperature, next_tok, next_prob);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+
+int mmst_sample_select(const float* logits, int ldl, int V, int B, int T, float temperature, uint32_t seed,
+                       uint32_t counter, int64_t* next_tok, float* next_prob, void* stream) {
+  if (!logits || !next_tok || !next_prob || V < 1 || V > 64 || B < 1 || T < 1 || !(temperature > 0.f))
+    return MMST_ERR_ARG;
+  hipLaunchKernelGGL(sample_select_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, B, T,
+                     temperature, seed, counter, next_tok, next_prob);
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

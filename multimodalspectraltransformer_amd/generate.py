@@ -160,6 +160,15 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
         _cross_kv(model, pl)
     emb, pe = ar.p32("embed_trg.weight"), ar.p32("pe_trg.weight")
     use_graph = (not sample) and os.environ.get("MMST_DECODE_GRAPH", "0") == "1"
+    # multinomial decode: the draw is part of the token step's launch (mmst_sample_select's rule: a pure function of
+    # seed, position and sequence); the seed of a decode comes from the caller's generator (torch's default one
+    # without), so seeded callers get the same tokens again.  MMST_SAMPLE_TORCH=1: softmax / multinomial / gather in
+    # torch per position instead.
+    sample_dev = sample and os.environ.get("MMST_SAMPLE_TORCH", "0") != "1"
+    seed = 0
+    if sample_dev:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator,
+                                 device=generator.device if generator is not None else "cpu"))
 
     fused = os.environ.get("MMST_DECODE_FUSED", "1") != "0"
 
@@ -171,6 +180,7 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
             direct = keep_logits is not None and not use_graph
             if direct:
                 stt.stack.logits = keep_logits[pos].data_ptr()
+            stt.stack.sample, stt.stack.sample_seed = int(sample_dev), seed
             stt.stack_step(tok[pos].data_ptr(), pe, pos, tok[pos + 1].data_ptr() if select else None,
                            prob[pos].data_ptr() if select else None, temperature)
             stt.stack.logits = stt.logits.data_ptr()
@@ -183,7 +193,12 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
             L.check(lib.mmst_decoder_layer_step(C.byref(pl.dec_p[l]), C.byref(s), 16, st()), "mmst_decoder_layer_step")
         stt.ops.gemm([dict(P=stt.out, Q=ar.pb("fc_out.weight"), C=stt.logits, bias=ar.p32("fc_out.bias"),
                            ldp=D, ldq=D, ldc=VPAD, Pn=B, Qn=VPAD, K=D, flags=L.GF_OUT_F32)], L.EPI_BIAS)
-        if select:
+        if select and sample_dev:
+            L.check(lib.mmst_sample_select(C.c_void_p(stt.logits.data_ptr()), VPAD, model.out_size, B, 1,
+                                           C.c_float(float(temperature)), C.c_uint32(seed), C.c_uint32(pos),
+                                           C.c_void_p(tok[pos + 1].data_ptr()), C.c_void_p(prob[pos].data_ptr()), st()),
+                    "mmst_sample_select")
+        elif select:
             L.check(lib.mmst_greedy_select(C.c_void_p(stt.logits.data_ptr()), VPAD, model.out_size, B, 1,
                                            C.c_float(float(temperature)), C.c_void_p(tok[pos + 1].data_ptr()),
                                            C.c_void_p(prob[pos].data_ptr()), st()), "mmst_greedy_select")
@@ -205,10 +220,10 @@ def _decode_plan_cached(model, pl, max_len, temperature, sos, early_stop, sample
             if keep_logits is not None:
                 keep_logits[pos].copy_(stt.logits)
         else:
-            enqueue(pos, not sample)
+            enqueue(pos, (not sample) or sample_dev)
             if use_graph and keep_logits is not None:
                 keep_logits[pos].copy_(stt.logits)
-            if sample:
+            if sample and not sample_dev:
                 p = torch.softmax(stt.logits[:, :model.out_size] / temperature, dim=1)
                 nxt = torch.multinomial(p, 1, generator=generator).squeeze(1)
                 tok[t].copy_(nxt)

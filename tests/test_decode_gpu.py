@@ -335,3 +335,53 @@ def test_beam_step_kernel_follows_the_reference_bookkeeping():
             assert int(nxt[0]["nbeams"][i]) == W
         cur, nxt = nxt, cur
     assert any(b[1][-1] == eos for bm in beams for b in bm)
+
+
+def _sample(logits, V, seed, counter, temperature=1.0):
+    B = logits.shape[0]
+    tok = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+    prob = torch.zeros(B, dtype=torch.float32, device="cuda")
+    L.check(L.lib().mmst_sample_select(C.c_void_p(logits.data_ptr()), logits.shape[1], V, B, 1, C.c_float(temperature),
+                                       C.c_uint32(seed), C.c_uint32(counter), C.c_void_p(tok.data_ptr()),
+                                       C.c_void_p(prob.data_ptr()), L.stream_ptr()), "mmst_sample_select")
+    return tok, prob
+
+
+def test_sample_select_distribution_and_reproducibility():
+    """mmst_sample_select against torch.softmax: 2048 draws per row (counter 0..2047) have the frequencies of the
+    row's distribution (4.5 standard deviations of a binomial proportion), the returned probability is that of the
+    chosen token, an index of probability zero is never drawn, and a draw is a pure function of (seed, counter, row)."""
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    V, B, N = 43, 24, 2048
+    logits = torch.randn(B, 64, generator=gen, device="cuda") * 2.0
+    logits[:, 5] = -float("inf")              # masked out: never drawn
+    logits[3, :V] = -float("inf")
+    logits[3, 17] = 0.5                       # a one-point distribution
+    logits[:, V:] = 50.0                      # padding columns beyond the vocabulary are not part of it
+    T = 0.7
+    p = torch.softmax(logits[:, :V] / T, dim=1)
+    counts = torch.zeros(B, V, device="cuda")
+    for c in range(N):
+        tok, prob = _sample(logits, V, 1234, c, T)
+        assert int(tok.min()) >= 0 and int(tok.max()) < V
+        counts.scatter_add_(1, tok.unsqueeze(1), torch.ones(B, 1, device="cuda"))
+        if c < 4:
+            assert torch.allclose(prob, p.gather(1, tok.unsqueeze(1)).squeeze(1), atol=1e-5)
+    freq = (counts / N).cpu()
+    pc = p.cpu()
+    sigma = torch.sqrt(pc * (1 - pc) / N)
+    assert bool(((freq - pc).abs() <= 4.5 * sigma + 1e-3).all()), float(((freq - pc).abs() - 4.5 * sigma).max())
+    assert float(freq[:, 5].max()) == 0.0 and float(freq[3, 17]) == 1.0
+    a, _ = _sample(logits, V, 99, 7, T)
+    b, _ = _sample(logits, V, 99, 7, T)
+    c_, _ = _sample(logits, V, 99, 8, T)
+    d, _ = _sample(logits, V, 100, 7, T)
+    assert torch.equal(a, b) and not torch.equal(a, c_) and not torch.equal(a, d)
+    # rows are independent: the same logits in every row do not give the same token in every row
+    same = logits[:1].expand(B, 64).contiguous()
+    t, _ = _sample(same, V, 5, 0, T)
+    assert len(set(t.tolist())) > 1
+    with pytest.raises(L.MMSTError):
+        L.check(L.lib().mmst_sample_select(C.c_void_p(logits.data_ptr()), 64, 65, B, 1, C.c_float(1.0), C.c_uint32(0),
+                                           C.c_uint32(0), C.c_void_p(a.data_ptr()), C.c_void_p(prob.data_ptr()),
+                                           L.stream_ptr()), "mmst_sample_select")

@@ -332,6 +332,23 @@ def test_teacher_forced_probabilities_and_multi_sample_multinomial():
     toks, probs = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config)
     assert toks.shape == (config.max_len, N) and probs.shape == (config.max_len - 1, N)
     assert float(probs.min()) > 0 and float(probs.max()) <= 1
+    # the draw is part of the token step's launch and a pure function of (seed, position, sequence): a seeded generator
+    # gives the same tokens again, another seed other tokens; the per-layer token step with the stand-alone selection
+    # launch draws the same tokens from its logits
+    g1 = torch.Generator(device="cuda").manual_seed(77)
+    ta, pa = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config, generator=g1)
+    tb, pb = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config,
+                                              generator=torch.Generator(device="cuda").manual_seed(77))
+    tc, _ = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config,
+                                             generator=torch.Generator(device="cuda").manual_seed(78))
+    assert torch.equal(ta, tb) and torch.equal(pa, pb) and not torch.equal(ta, tc)
+    os.environ["MMST_DECODE_FUSED"] = "0"
+    try:
+        td, _ = gen.multinomial_sequence_multi_2(model, memory, mask, stoi, config,
+                                                 generator=torch.Generator(device="cuda").manual_seed(77))
+    finally:
+        del os.environ["MMST_DECODE_FUSED"]
+    assert float((td[:fitted] == ta[:fitted]).float().mean()) > 0.97
     # a confident model: sampling mostly reproduces the greedy tokens (one unlucky draw sends a molecule elsewhere)
     assert float((toks.cpu()[:fitted] == torch.from_numpy(g["tokens"])[:fitted]).float().mean()) > 0.6
 

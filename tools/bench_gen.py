@@ -43,5 +43,15 @@ with torch.no_grad():
         same = "" if ref is None else (" tokens equal: %s" % bool(torch.equal(toks, ref)))
         if ref is None:
             ref = toks.clone()
+        if os.environ.get("GEN_STAMPS") and split:
+            # timing build of the library (-DMMST_DEC_STAMP): room for the stamps behind the workspace, one more decode
+            stt = pl._step_state
+            n = stt.stack_ws.numel()
+            stt.stack_ws = torch.zeros(n + 64, dtype=torch.float32, device="cuda")
+            stt.stack.ffn_ws = stt.stack_ws.data_ptr()
+            gen._decode_plan(model, pl, T, 1.0, 3, early_stop=False)
+            torch.cuda.synchronize()
+            st = stt.stack_ws[n:n + 20].view(torch.int64).cpu().numpy()
+            print("stamps of the layer-2 launch at the last position (cycles from entry):", [int(x - st[0]) for x in st[:10]])
         print("%-14s %d molecules x %d positions: %.2f ms (%.1f us per position)%s" % (name, B, T, dt * 1e3, dt * 1e6 / T, same),
               flush=True)
