@@ -290,10 +290,12 @@ def beam_case(M, vg, name, mode, nl, B, seed, wseed, gain, beam_size, gen_len):
     print(name, 'margins', margins, 'best', seqs[0, 0], scores[0])
 
 
-def clip_case(M, name, mode, nl, B, seed, wseed, hseed):
+def clip_case(M, name, mode, nl, B, seed, wseed, hseed, big=False):
     """Reference CLIPModel.forward (models_CLIP_v15_4.py:243-302) in eval mode with the ChemBERTa branch replaced
     by given features (its weights are not in the repository): loss, per-sample losses and gradients of the
-    projection heads, of fp1 and of a few encoder tensors."""
+    projection heads, of fp1 and of a few encoder tensors.  big: the configuration's own size (CLIP_batch_size 128,
+    6 layers); gradient digests carry 512 samples each (the tests there cannot afford the oracle's backward pass) and
+    the sampler vectors are left to the small fixture."""
     import utils_MMT.models_CLIP_v15_4 as CL
     cfg = ref_config(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl, drop_out=0.1)
     ocfg = O.default_cfg(training_mode=mode, num_encoder_layers=nl, num_decoder_layers=nl)
@@ -326,7 +328,12 @@ def clip_case(M, name, mode, nl, B, seed, wseed, hseed):
                 'MT_model.fp1.weight', 'MT_model.fp1.bias', 'MT_model.encoder_cross.layers.0.linear1.weight',
                 'MT_model.encoder_1H.layers.0.self_attn.in_proj_weight',
                 'MT_model.linear_spec_embedding_HSQC.point_embedding_layer_HSQC.fc_HSQC.weight'):
-            out['grad/' + k] = digest(p.grad)
+            out['grad/' + k] = digest(p.grad, 512 if big else 96)
+    if big:
+        for k in ('MT_model.encoder_cross.layers.5.linear2.weight', 'MT_model.encoder_cross.layers.3.self_attn.out_proj.weight',
+                  'MT_model.encoder_COSY.layers.2.linear1.weight', 'MT_model.encoder_HSQC.layers.5.self_attn.in_proj_weight',
+                  'MT_model.encoder_1H.layers.3.norm1.weight', 'MT_model.linear_embedding_MW.linear_spec_embedding_MW.weight'):
+            out['grad/' + k] = digest(dict(clip.named_parameters())[k].grad, 512)
     # the oracle restatement must agree before the fixture is written
     ohead = {k: v.clone().requires_grad_(True) for k, v in head.items()}
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -337,6 +344,10 @@ def clip_case(M, name, mode, nl, B, seed, wseed, hseed):
     g2 = ohead['MT_projection.fc.weight'].grad
     err = float((g2 - g1).abs().max() / g1.abs().max())
     assert err < 1e-3, err
+    if big:
+        np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+        print(name, 'loss', float(loss), 'losses', np_(losses.detach())[:4])
+        return
     # MW-sorted batch sampler of the CLIP training loop (clip_functions_v15_4.py:117-152), seeded global RNG
     import random
     import pandas as pd
@@ -568,6 +579,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'clip':      # only the CLIP-head fixture
         clip_case(M, 'clip_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=41, wseed=401, hseed=402)
         clip_train_case(M, 'clip_train_c2_L1', '1H_HSQC_COSY_IR_MF_MW', 1, 6, seed=42, wseed=403, hseed=404)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'clip_full':  # the contrastive configuration at its size (minutes, ~25 GB)
+        clip_case(M, 'clip_c2_full', '1H_HSQC_COSY_IR_MF_MW', 6, 128, seed=43, wseed=405, hseed=406, big=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'real_data':
         real_data_case(M)
