@@ -169,7 +169,21 @@ def additive_mask(mask):
     return mask.to(torch.float32)
 
 
-def attention(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, key_bias=None, causal=False):
+# Train mode.  torch's layers apply dropout at fixed sites (nn.MultiheadAttention: the attention probabilities;
+# nn.Transformer{En,De}coderLayer: dropout1/2/3 on the sub-block outputs and `dropout` on the hidden activation;
+# models_MMT_v15_4.py:961: dropout2 on the target embedding).  The functions below are those layers with dropout OFF
+# unless DROPOUT is set: DROPOUT(x, (module prefix, kind)) -> x with the caller's mask and scale applied, kind in
+# "attn" (x = probabilities (B,H,T,S)), "out1" / "out2" / "out3", "hidden", "embed" (x sequence-first (T,B,n)).  A test
+# that knows which mask a run used at every site (the HIP path's masks are pure functions of seed and index) can so
+# replay that run's train-mode step here and compare by value.
+DROPOUT = None
+
+
+def _drop(x, prefix, kind):
+    return x if DROPOUT is None else DROPOUT(x, (prefix, kind))
+
+
+def attention(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, key_bias=None, causal=False, site=None):
     """nn.MultiheadAttention (batch_first=False) on sequence-first tensors.
 
     q_in (T,B,d), kv_in (S,B,d); key_bias (B,S) additive float or None.
@@ -190,6 +204,8 @@ def attention(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, key_bias=None, causa
         cm = torch.triu(torch.full((T, S), NEG_INF), diagonal=1)
         s = s + cm
     p = torch.softmax(s, dim=-1)
+    if site is not None:
+        p = _drop(p, site, "attn")
     o = p @ v  # B,H,T,hd
     o = o.permute(2, 0, 1, 3).reshape(T, B, d)
     return linear(o, w_out, b_out)
@@ -200,11 +216,11 @@ def encoder_layer(x, sd, pre, nhead, key_bias):
     dropout off (eval / p=0)."""
     sa = attention(x, x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"],
                    sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"],
-                   nhead, key_bias)
-    x = layer_norm(x + sa, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
-    h = torch.relu(linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+                   nhead, key_bias, site=pre + "self_attn")
+    x = layer_norm(x + _drop(sa, pre, "out1"), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+    h = _drop(torch.relu(linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])), pre, "hidden")
     ff = linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
-    return layer_norm(x + ff, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+    return layer_norm(x + _drop(ff, pre, "out2"), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
 
 
 def encoder(x, sd, name, nlayers, nhead, mask):
@@ -217,15 +233,15 @@ def encoder(x, sd, name, nlayers, nhead, mask):
 def decoder_layer(x, mem, sd, pre, nhead, mem_bias):
     sa = attention(x, x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"],
                    sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"],
-                   nhead, None, causal=True)
-    x = layer_norm(x + sa, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+                   nhead, None, causal=True, site=pre + "self_attn")
+    x = layer_norm(x + _drop(sa, pre, "out1"), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
     ca = attention(x, mem, sd[pre + "multihead_attn.in_proj_weight"], sd[pre + "multihead_attn.in_proj_bias"],
                    sd[pre + "multihead_attn.out_proj.weight"], sd[pre + "multihead_attn.out_proj.bias"],
-                   nhead, mem_bias)
-    x = layer_norm(x + ca, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
-    h = torch.relu(linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+                   nhead, mem_bias, site=pre + "multihead_attn")
+    x = layer_norm(x + _drop(ca, pre, "out2"), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+    h = _drop(torch.relu(linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])), pre, "hidden")
     ff = linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
-    return layer_norm(x + ff, sd[pre + "norm3.weight"], sd[pre + "norm3.bias"])
+    return layer_norm(x + _drop(ff, pre, "out3"), sd[pre + "norm3.weight"], sd[pre + "norm3.bias"])
 
 
 def decoder(x, mem, sd, nlayers, nhead, mem_mask):
@@ -343,7 +359,7 @@ def decode_logits(sd, cfg, trg, memory, mask):
     """Target embedding + decoder + vocabulary projection
     (models_MMT_v15_4.py:955-974)."""
     T, _ = trg.shape
-    e = sd["embed_trg.weight"][trg] + sd["pe_trg.weight"][torch.arange(T)].unsqueeze(1)
+    e = _drop(sd["embed_trg.weight"][trg] + sd["pe_trg.weight"][torch.arange(T)].unsqueeze(1), "embed_trg", "embed")
     out = decoder(e, memory, sd, cfg["num_decoder_layers"], cfg["num_heads"], mask)
     return linear(out, sd["fc_out.weight"], sd["fc_out.bias"])
 
