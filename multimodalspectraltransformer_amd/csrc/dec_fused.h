@@ -54,6 +54,24 @@ struct DecFusedLn {
   int B, T;
   float drop_p;
 };
+// self : (dz1, dzd1) = LayerNorm-1 backward of (dqc Wcq + dz2); da = dzd1 Wo; causal self-attention backward -> dqkv;
+//        dx = dqkv Wqkv + dz1, which is either the output (bottom layer: z3 == NULL) or goes through the LayerNorm-3
+//        backward of the layer below (its dz3 / dzd3 and gamma / beta gradients).  One launch in place of the second
+//        `ln` launch, the attention launch and the first part of the next `mid` launch.
+struct DecFusedSelf {
+  const void* dqc; const void* ft_cq; const void* dz2;              // input rows, image of Wcq^T, residual
+  const void* z1; const float* st1; const float* g1; float* dg1; float* dbe1;
+  void* dz1; void* dzd1;
+  const void* ft_o;                                                 // image of Wo^T
+  const void* qkv; const void* attn1; const float* lse1; void* dqkv;
+  const void* ft_qkv;                                               // image of Wqkv^T
+  const void* z3; const float* st3; const float* g3; float* dg3; float* dbe3; void* dz3; void* dzd3;   // layer below, or NULL
+  void* dx;                                                         // bottom layer: dx rows [B*T][128]
+  uint32_t seed, seed_below;                                        // layer seeds (sites are added to them)
+  int B, T;
+  float drop_p;
+};
+int launch_dec_bwd_self(const DecFusedSelf& a, hipStream_t stream);
 int launch_dec_bwd_mid(const DecFusedBwd& a, hipStream_t stream);
 int launch_dec_bwd_ln(const DecFusedLn& a, hipStream_t stream);
 bool dec_fused_enabled();   // environment MMST_DEC_FUSED (default on), or what dec_fused_set() said last

@@ -931,6 +931,345 @@ __global__ __launch_bounds__(NTHR) void dec_bwd_ln_kernel(const DecFusedLn a) {
   }
 }
 
+
+// ---- start of a layer's backward below the cross-attention, one workgroup per molecule:
+//   (dz1, dzd1) = LayerNorm-1 backward of (dqc Wcq + dz2);  da = dzd1 Wo
+//   causal self-attention backward from da, the saved Q|K|V rows, attention output and row statistics -> dqkv
+//   dx = dqkv Wqkv + dz1;  DOWN: (dz3, dzd3) of the layer BELOW = its LayerNorm-3 backward of dx;  else dx is the output
+// Self-attention, head_dim 8, on v_mfma_f32_32x32x16_bf16 with the contraction zero-padded to 16; wave w serves heads
+// 2 w and 2 w + 1.  The probabilities are recomputed in BOTH orientations, so that no score matrix is ever transposed:
+//   query on the lane, 32 keys of a tile on the registers:  S^T = K Q^T, dP^T = V dO^T  ->  dQ^T += K^T dS
+//   key on the lane, 32 queries of a tile on the registers: S = Q K^T,   dP = dO V^T    ->  dK^T += Q^T dS, dV^T += dO^T P
+// (the second operand of each product is the score registers themselves; the first comes from transposed images
+// K^T / Q^T / dO^T [feature][token], read in the register order of the scores).  dQ / dK / dV replace the head's
+// Q / K / V columns of the row image in place (no other wave reads them), which then is the token side of the
+// projection down.
+constexpr int SELF_TAB = 16 * TM * 4;   // one [head][token] table
+constexpr int SELF_SMEM = TM * QS + X_BYTES + D * VS + 2 * D * VS + 3 * SELF_TAB + (2 * D + 2048) * 4;
+static_assert(2 * D * VS >= TM * ZS * 4, "fp32 scratch inside the transposed images' region");
+static_assert(SELF_SMEM <= 160 * 1024, "LDS of one compute unit");
+
+// 8 values of row `row` of a transposed image for the contraction step (tile kt, half st2) in the register order of a
+// score tile: tokens 32 kt + 16 st2 + 4 hf + {0..3} and the same + 8
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row, int kt, int st2, int hf) {
+  const unsigned char* vp = img + row * VS + (32 * kt + 16 * st2 + 4 * hf) * 2;
+  const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 16);
+  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+template <bool DOWN>
+__global__ __launch_bounds__(NTHR) void dec_bwd_self_kernel(const DecFusedSelf a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SELF_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, T = a.T, m0 = b * T;
+  const float dp = a.drop_p;
+  const uint32_t thr = drop_threshold(dp);
+  const float dscale = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  unsigned char* const QKV = smem;                       // Q|K|V rows, later dQ|dK|dV
+  unsigned char* const R1 = QKV + TM * QS;               // dqc rows, then dO rows
+  unsigned char* const R2 = R1 + X_BYTES;                // dzd1 rows, then dO^T
+  unsigned char* const R3 = R2 + D * VS;                 // fp32 scratch; K^T | Q^T while the attention runs
+  float* const Zf = reinterpret_cast<float*>(R3);
+  unsigned char* const Kt = R3;
+  unsigned char* const Qt = R3 + D * VS;
+  float* const lse_s = reinterpret_cast<float*>(R3 + 2 * D * VS);   // [16][64]
+  float* const delta_s = lse_s + 16 * TM;
+  uint32_t* const rs_s = reinterpret_cast<uint32_t*>(delta_s + 16 * TM);
+  float* const vec = reinterpret_cast<float*>(rs_s + 16 * TM);     // gamma1 | gamma3
+  float* const red = vec + 2 * D;
+  const int t_ = tid >> 3, c0_ = (tid & 7) * 16;
+  const bool ok_ = t_ < T;
+  const size_t row = (size_t)(m0 + (ok_ ? t_ : T - 1));
+#ifdef DEC_X_STAMP
+  unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>((bf16*)a.dqkv + (size_t)a.B * T * 3 * D);
+#endif
+  STAMP(0);
+
+  // ---- everything the first part reads is requested before anything is waited for ----
+  uint4 rv[2], qv[6];
+  rows_issue(rv, (const bf16*)a.dqc + (size_t)m0 * D, T, tid);
+  bf16x8 res[2], zr[2], orow[2];
+  load_res(res, (const bf16*)a.dz2 + (size_t)m0 * D, T, tid);
+  load_res(zr, (const bf16*)a.z1 + (size_t)m0 * D, T, tid);
+  const float mean = a.st1[2 * row], rstd = a.st1[2 * row + 1];
+  const float gv = tid < D ? a.g1[tid] : (DOWN ? a.g3[tid & 127] : 0.f);
+  bf16x8 wi[1][4], wo[1][4];
+  load_w<1, 4>(wi, (const bf16*)a.ft_cq, wave, D / 32, 0, lane);
+  load_w<1, 4>(wo, (const bf16*)a.ft_o, wave, D / 32, 0, lane);
+  order_point();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int i = tid + k * NTHR, t = i / 48, c = i % 48;
+    qv[k] = *reinterpret_cast<const uint4*>((const bf16*)a.qkv + (size_t)(m0 + (t < T ? t : T - 1)) * 3 * D + c * 8);
+  }
+  load_res(orow, (const bf16*)a.attn1 + (size_t)m0 * D, T, tid);
+  float lsev[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + k * NTHR, hh = i >> 6, q = i & 63;
+    lsev[k] = a.lse1[(size_t)(b * 16 + hh) * T + (q < T ? q : T - 1)];
+  }
+  order_point();
+  if (tid < 2 * D) vec[tid] = gv;
+  rows_commit(R1, rv, T, tid);
+  lds_barrier();   // (the Q|K|V rows and the tables are stored further down: their loads land beside the first product)
+  STAMP(1);
+  // ---- norm1 backward ----
+  float dy[16], dz[16], pg[16], pb[16];
+  {
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_tok<1, 4>(acc, wi, R1, XS, lane);
+    acc_to_scratch(acc, Zf, 16 * wave, lane);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Zf + t_ * ZS + c0_ + 4 * j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * j + e;
+      dy[i] = ok_ ? v[e] + (float)res[i >> 3][i & 7] : 0.f;
+      pg[i] = 0.f;
+      pb[i] = 0.f;
+    }
+  }
+  lnbwd_core(dy, zr, mean, rstd, vec, c0_, ok_, dz, pg, pb);
+  store_dz(dz, (bf16*)a.dz1 + (size_t)m0 * D, dp > 0.f ? (bf16*)a.dzd1 + (size_t)m0 * D : nullptr, R2, m0 + t_, t_, c0_, ok_,
+           a.seed + 1, thr, dscale);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int i = tid + k * NTHR, t = i / 48, c = i % 48;
+    *reinterpret_cast<uint4*>(QKV + t * QS + c * 16) = t < T ? qv[k] : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + k * NTHR, hh = i >> 6, q = i & 63;
+    lse_s[i] = q < T ? lsev[k] : 1.0e30f;    // rows past the end: every probability 0
+    rs_s[i] = attn_row_seed(a.seed + 0, (uint32_t)((b * 16 + hh) * T + q));
+  }
+  lnbwd_colsums(pg, pb, a.dg1, a.dbe1, red, tid, true);   // (its barrier also completes the dzd1 and the Q|K|V image)
+  STAMP(2);
+  // ---- da = dzd1 Wo: rows into R1, transposed into R2 (which the product reads: a barrier in between) ----
+  {
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_tok<1, 4>(acc, wo, R2, XS, lane);
+    lds_barrier();
+    const int n = 16 * wave + 4 * g;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int t = mt * 16 + r;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[0][mt][e];
+      const uint2 pk = pack4(v);
+      *reinterpret_cast<uint2*>(R1 + t * XS + n * 2) = pk;
+      unsigned short* tp = reinterpret_cast<unsigned short*>(R2 + n * VS + t * 2);
+      tp[0] = (unsigned short)(pk.x & 0xFFFFu);
+      tp[VS / 2] = (unsigned short)(pk.x >> 16);
+      tp[2 * (VS / 2)] = (unsigned short)(pk.y & 0xFFFFu);
+      tp[3 * (VS / 2)] = (unsigned short)(pk.y >> 16);
+    }
+  }
+  STAMP(3);
+  // K^T and Q^T from the row image (the fp32 scratch is free since the rows were read)
+  // (a thread takes two neighbouring tokens of one 8-column chunk, so that it writes whole 32-bit words, and the lanes of
+  // a wave take neighbouring token pairs of the same chunk, so that a write instruction covers contiguous words)
+  for (int i = tid; i < (TM / 2) * 32; i += NTHR) {
+    const int tp2 = i & 31, c = i >> 5;                // chunk c: columns 8 c .. of Q (c < 16) or K
+    const uint4 u0 = __builtin_bit_cast(uint4, lds8(QKV + (2 * tp2) * QS + c * 16));
+    const uint4 u1 = __builtin_bit_cast(uint4, lds8(QKV + (2 * tp2 + 1) * QS + c * 16));
+    uint32_t* wp = reinterpret_cast<uint32_t*>((c < 16 ? Qt : Kt) + ((c & 15) * 8) * VS + tp2 * 4);
+    const uint32_t a0[4] = {u0.x, u0.y, u0.z, u0.w}, a1[4] = {u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wp[(2 * e) * (VS / 4)] = (a0[e] & 0xFFFFu) | (a1[e] << 16);
+      wp[(2 * e + 1) * (VS / 4)] = (a0[e] >> 16) | (a1[e] & 0xFFFF0000u);
+    }
+  }
+  lds_barrier();
+  // delta[head][q] = sum over the head's 8 columns of dO * O (O: the saved attention output)
+  {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16x8 dov = lds8(R1 + t_ * XS + (c0_ + 8 * j) * 2);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)dov[e] * (float)orow[j][e];
+      delta_s[((c0_ >> 3) + j) * TM + t_] = ok_ ? s : 0.f;
+    }
+  }
+  lds_barrier();
+  STAMP(4);
+  // ---- self-attention backward ----
+  {
+    const int r32 = lane & 31, hf = lane >> 5;
+    const float scale = rsqrtf(8.0f), scale2 = scale * LOG2E;
+#pragma unroll 1
+    for (int hi = 0; hi < 2; ++hi) {
+      const int hh = 2 * wave + hi, hoff = hh * 8;
+      float dq4[2][4], dk4[2][4], dv4[2][4];
+      // query on the lane -> dQ
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = 32 * qt + r32;
+        const bf16x8 qf = hf == 0 ? lds8(QKV + q * QS + hoff * 2) : zero8();
+        const bf16x8 dof = hf == 0 ? lds8(R1 + q * XS + hoff * 2) : zero8();
+        const float lq = lse_s[hh * TM + q], dl = delta_s[hh * TM + q];
+        const uint32_t rs = rs_s[hh * TM + q];
+        f32x16 oacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt <= qt; ++kt) {
+          const bf16x8 kf = hf == 0 ? lds8(QKV + (32 * kt + r32) * QS + (D + hoff) * 2) : zero8();
+          const bf16x8 vf = hf == 0 ? lds8(QKV + (32 * kt + r32) * QS + (2 * D + hoff) * 2) : zero8();
+          f32x16 sa, da_;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sa[i] = 0.f; da_[i] = 0.f; }
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sa, 0, 0, 0);
+          da_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof, da_, 0, 0, 0);
+          float ds[16];
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const int key = 32 * kt + acc_row(i, hf);
+            const uint32_t hb = attn_pair_bits(rs, (uint32_t)(key >> 1) * ATTN_PAIR_MUL);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float pr = (key + e) <= q ? __builtin_amdgcn_exp2f(sa[i + e] * scale2 - lq) : 0.f;
+              const bool keep = (e ? (hb >> 16) : (hb & 0xFFFFu)) >= thr;
+              ds[i + e] = pr * ((keep ? da_[i + e] * dscale : 0.f) - dl) * scale;
+            }
+          }
+#pragma unroll
+          for (int st2 = 0; st2 < 2; ++st2) {
+            const bf16x8 ktf = r32 < 8 ? tr_frag(Kt, hoff + r32, kt, st2, hf) : zero8();
+            bf16x8 dsf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsf[j] = (bf16)ds[8 * st2 + j];
+            oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, oacc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dq4[qt][j] = oacc[j];
+      }
+      // key on the lane -> dK, dV
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key = 32 * kt + r32;
+        const bf16x8 kf = hf == 0 ? lds8(QKV + key * QS + (D + hoff) * 2) : zero8();
+        const bf16x8 vf = hf == 0 ? lds8(QKV + key * QS + (2 * D + hoff) * 2) : zero8();
+        f32x16 kacc, vacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { kacc[i] = 0.f; vacc[i] = 0.f; }
+#pragma unroll
+        for (int qt = kt; qt < 2; ++qt) {
+          const bf16x8 qf = hf == 0 ? lds8(QKV + (32 * qt + r32) * QS + hoff * 2) : zero8();
+          const bf16x8 dof = hf == 0 ? lds8(R1 + (32 * qt + r32) * XS + hoff * 2) : zero8();
+          f32x16 sb, db;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sb[i] = 0.f; db[i] = 0.f; }
+          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sb, 0, 0, 0);
+          db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, db, 0, 0, 0);
+          float pd[16], ds[16];
+          // the registers' queries come in runs of four (acc_row): their table entries are read as 16-byte pieces
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          f32x4 lq4[4], dl4[4];
+          u32x4_t rs4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q0 = hh * TM + 32 * qt + 8 * j + 4 * hf;
+            lq4[j] = *reinterpret_cast<const f32x4*>(lse_s + q0);
+            dl4[j] = *reinterpret_cast<const f32x4*>(delta_s + q0);
+            rs4[j] = *reinterpret_cast<const u32x4_t*>(rs_s + q0);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int q = 32 * qt + acc_row(i, hf);
+            const float lq = lq4[i >> 2][i & 3], dl = dl4[i >> 2][i & 3];
+            const uint32_t hb = attn_pair_bits(rs4[i >> 2][i & 3], (uint32_t)(key >> 1) * ATTN_PAIR_MUL);
+            const bool keep = ((key & 1) ? (hb >> 16) : (hb & 0xFFFFu)) >= thr;
+            const float pr = key <= q ? __builtin_amdgcn_exp2f(sb[i] * scale2 - lq) : 0.f;
+            pd[i] = keep ? pr * dscale : 0.f;
+            ds[i] = pr * ((keep ? db[i] * dscale : 0.f) - dl) * scale;
+          }
+#pragma unroll
+          for (int st2 = 0; st2 < 2; ++st2) {
+            const bf16x8 qtf = r32 < 8 ? tr_frag(Qt, hoff + r32, qt, st2, hf) : zero8();
+            const bf16x8 dotf = r32 < 8 ? tr_frag(R2, hoff + r32, qt, st2, hf) : zero8();
+            bf16x8 dsf, pdf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dsf[j] = (bf16)ds[8 * st2 + j]; pdf[j] = (bf16)pd[8 * st2 + j]; }
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, kacc, 0, 0, 0);
+            vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pdf, vacc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dk4[kt][j] = kacc[j]; dv4[kt][j] = vacc[j]; }
+      }
+      // the head's gradients replace its Q / K / V columns (this wave is their only reader)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 32 * tt + r32;
+        *reinterpret_cast<uint2*>(QKV + t * QS + (hoff + 4 * hf) * 2) = pack4(dq4[tt]);
+        *reinterpret_cast<uint2*>(QKV + t * QS + (D + hoff + 4 * hf) * 2) = pack4(dk4[tt]);
+        *reinterpret_cast<uint2*>(QKV + t * QS + (2 * D + hoff + 4 * hf) * 2) = pack4(dv4[tt]);
+      }
+    }
+  }
+  STAMP(5);
+  // ---- dx = dqkv Wqkv + dz1 (this lane's dz1 columns: its own stores of the first part) ----
+  // (requested only now: held across the attention they cost 48 registers, which then spills)
+  bf16x8 wq[1][12];
+  load_w<1, 12>(wq, (const bf16*)a.ft_qkv, wave, 3 * D / 32, 0, lane);
+  bf16x8 res1[2], z3r[2];
+  load_res(res1, (const bf16*)a.dz1 + (size_t)m0 * D, T, tid);
+  float mean3 = 0.f, rstd3 = 0.f;
+  if constexpr (DOWN) {
+    load_res(z3r, (const bf16*)a.z3 + (size_t)m0 * D, T, tid);
+    mean3 = a.st3[2 * row];
+    rstd3 = a.st3[2 * row + 1];
+  }
+  lds_barrier();
+  store_rows<3 * D, QS>((bf16*)a.dqkv + (size_t)m0 * 3 * D, 3 * D, QKV, T, tid);
+  {
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_tok<1, 12>(acc, wq, QKV, QS, lane);
+    acc_to_scratch(acc, Zf, 16 * wave, lane);
+  }
+  lds_barrier();
+  STAMP(6);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Zf + t_ * ZS + c0_ + 4 * j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * j + e;
+      dy[i] = ok_ ? v[e] + (float)res1[i >> 3][i & 7] : 0.f;
+      pg[i] = 0.f;
+      pb[i] = 0.f;
+    }
+  }
+  if constexpr (DOWN) {
+    lnbwd_core(dy, z3r, mean3, rstd3, vec + D, c0_, ok_, dz, pg, pb);
+    store_dz(dz, (bf16*)a.dz3 + (size_t)m0 * D, dp > 0.f ? (bf16*)a.dzd3 + (size_t)m0 * D : nullptr, R1, m0 + t_, t_, c0_, ok_,
+             a.seed_below + 5, thr, dscale);
+    lnbwd_colsums(pg, pb, a.dg3, a.dbe3, red, tid, true);
+  } else if (ok_) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)dy[8 * j + e];
+      *reinterpret_cast<bf16x8*>((bf16*)a.dx + (size_t)(m0 + t_) * D + c0_ + 8 * j) = o;
+    }
+  }
+  STAMP(7);
+}
+
 }  // namespace
 
 namespace {
@@ -959,6 +1298,14 @@ int launch_dec_bwd_mid(const DecFusedBwd& a, hipStream_t stream) {
   if (a.B < 1 || a.T < 1 || a.T > TM || !a.ws) return MMST_ERR_ARG;
   if (a.up_dqkv) MMST_LAUNCH((dec_bwd_mid_kernel<true>), dim3(a.B * DEC_FFN_PARTS), dim3(NTHR), 0, stream, a);
   else MMST_LAUNCH((dec_bwd_mid_kernel<false>), dim3(a.B * DEC_FFN_PARTS), dim3(NTHR), 0, stream, a);
+  MMST_CHECK_LAUNCH();
+  return MMST_OK;
+}
+int launch_dec_bwd_self(const DecFusedSelf& a, hipStream_t stream) {
+  if (a.B < 1 || a.T < 1 || a.T > TM || !a.dqc || !a.qkv || !a.dqkv || !a.ft_qkv) return MMST_ERR_ARG;
+  if (a.z3) MMST_LAUNCH((dec_bwd_self_kernel<true>), dim3(a.B), dim3(NTHR), 0, stream, a);
+  else if (a.dx) MMST_LAUNCH((dec_bwd_self_kernel<false>), dim3(a.B), dim3(NTHR), 0, stream, a);
+  else return MMST_ERR_ARG;
   MMST_CHECK_LAUNCH();
   return MMST_OK;
 }

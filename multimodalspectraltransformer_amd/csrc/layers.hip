@@ -933,6 +933,9 @@ int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, cons
   hipEvent_t dmem_done = nullptr;
   hipEvent_t layer_done[MMST_MAX_LAYERS];
   static const bool use_third = [] { const char* e = getenv("MMST_DEC_THIRD_STREAM"); return e ? atoi(e) != 0 : true; }();
+  // norm1 backward, the self-attention backward and the projection down to the layer below in ONE launch per layer
+  // (MMST_DEC_SELF_FUSED=0: three launches, the attention among them as a launch of attn.hip)
+  static const bool self_fused = [] { const char* e = getenv("MMST_DEC_SELF_FUSED"); return e ? atoi(e) != 0 : true; }();
   hipStream_t xst = use_third ? third_stream() : nullptr;
   for (int l = nl - 1; l >= 0; --l) {
     const mmst_dec_params& P = *p[l];
@@ -943,7 +946,7 @@ int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, cons
       DecFusedBwd m;
       memset(&m, 0, sizeof(m));
       m.p = P; m.g = G; m.a = A; m.w = W; m.seed = seeds[l];
-      if (l + 1 < nl) { m.up_dqkv = w[l + 1]->dqkv; m.up_dz1 = w[l + 1]->dz1; m.up_ft_qkv = p[l + 1]->ft_qkv; }
+      if (l + 1 < nl && !self_fused) { m.up_dqkv = w[l + 1]->dqkv; m.up_dz1 = w[l + 1]->dz1; m.up_ft_qkv = p[l + 1]->ft_qkv; }
       m.B = B; m.T = T; m.drop_p = drop_p; m.ws = A.ffn_ws;
       RUN(launch_dec_bwd_mid(m, st));
     }
@@ -983,6 +986,23 @@ int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, cons
       RUN(launch_gemm(gk, EPI_BIAS, false, true, wst));
       if (l == 0) RUN(stream_fork(wst, nullptr, &dmem_done));
     }
+    hipEvent_t done = nullptr;
+    if (self_fused) {
+      DecFusedSelf k;
+      memset(&k, 0, sizeof(k));
+      k.dqc = W.dqc; k.ft_cq = P.ft_cqkv; k.dz2 = W.dz2; k.z1 = A.z1; k.st1 = A.st1; k.g1 = P.g1; k.dg1 = G.g1; k.dbe1 = G.be1;
+      k.dz1 = W.dz1; k.dzd1 = W.dzd1; k.ft_o = P.ft_o;
+      k.qkv = A.qkv; k.attn1 = A.attn1; k.lse1 = A.lse1; k.dqkv = W.dqkv; k.ft_qkv = P.ft_qkv;
+      if (l > 0) {
+        k.z3 = a[l - 1]->z3; k.st3 = a[l - 1]->st3; k.g3 = p[l - 1]->g3; k.dg3 = g[l - 1]->g3; k.dbe3 = g[l - 1]->be3;
+        k.dz3 = (void*)w[l - 1]->dz3; k.dzd3 = (void*)w[l - 1]->dzd3; k.seed_below = seeds[l - 1];
+      } else {
+        k.dx = W.dx;
+      }
+      k.seed = seeds[l]; k.B = B; k.T = T; k.drop_p = drop_p;
+      done = arm_completion_event();
+      RUN(launch_dec_bwd_self(k, st));
+    } else {
     {   // norm1 backward, self-attention out_proj backward
       DecFusedLn k;
       memset(&k, 0, sizeof(k));
@@ -1003,7 +1023,6 @@ int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, cons
       q.dQ = dqkv; q.dK = dqkv + D; q.dV = dqkv + 2 * D; q.lddq = q.lddk = q.lddv = 3 * D;
       q.B = B; q.H = nhead; q.Tq = T; q.Sk = T; q.seed = seeds[l] + 0;
     }
-    hipEvent_t done = nullptr;
     if (l > 0) done = arm_completion_event();
     RUN(launch_attn_bwd(ab, st));
     if (l == 0) {   // the bottom layer: gradient at the target embedding
@@ -1014,6 +1033,7 @@ int mmst_decoder_stack_bwd_streams(int nl, const mmst_dec_params* const* p, cons
       gb.p[0] = q;
       done = arm_completion_event();
       RUN(launch_gemm(gb, EPI_BIAS, false, true, st));
+    }
     }
     // The layer's parameter gradients: not on wstream, where they would sit in front of the next layer's dK / dV pass
     // (the chain of those passes, each waiting for its layer's dQ kernel, is what the encoder's backward waits for),
