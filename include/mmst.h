@@ -6,7 +6,11 @@
  * listed here: (1) a ring of 64 HIP events per device, created on the first two-stream call
  * (*_bwd_streams) and reused for the stream hand-offs; (2) the process-wide kernel-path switches
  * and the diagnostic event tap of mmst_lowlevel.h; (3) the per-device static scratch array of the
- * one *_static entry point.  None of the three is visible in results.
+ * one *_static entry point; (4) one non-blocking HIP stream per device, created on first use by
+ * mmst_decoder_stack_bwd_streams / mmst_train_step: the decoder's parameter gradients and the
+ * optimizer updates of finished gradient segments run on it beside the caller's two streams, and it
+ * is joined into them before those calls' work counts as complete on the caller's streams.  None of
+ * the four is visible in results.
  * The building-block launchers underneath (grouped GEMM, attention, fused feed-forward) are
  * declared in mmst_lowlevel.h.
  *
@@ -477,6 +481,12 @@ typedef struct {
   int n_ffn; uint32_t ffn1_off[MMST_MAX_FFN]; uint32_t ffn2_off[MMST_MAX_FFN];   /* linear1 / linear2 offsets in Pb */
   /* fragment-major weight images to refresh after the optimizer (the f_* / ft_* of dec_p), or n_frag = 0 */
   int n_frag; mmst_frag_desc frag[MMST_MAX_FRAG];
+  /* Element offsets in the flat buffers at which the gradient segments start, in the order backward completes them from
+   * the top: decoder + heads [seg_decoder, end), cross encoder [seg_cross, seg_decoder), modality encoders of depth l
+   * [seg_modal[l], seg_modal[l + 1]) with seg_modal[n_enc_layers] = seg_cross, embeddings [0, seg_modal[0]).  With
+   * them (seg_decoder > 0) the optimizer of a fused step updates a segment as soon as its gradient is final, beside the
+   * rest of backward, on a stream of the library's own; all zero: one optimizer launch at the end. */
+  long seg_decoder, seg_cross, seg_modal[MMST_MAX_LAYERS + 1];
 } mmst_step_plan;
 
 typedef struct {

@@ -227,7 +227,8 @@ class StepPlan(C.Structure):
                       "dmem", "dmem_in", "dtrg", "P", "G", "M", "V", "Pb", "PbT") +
                 [("n_ranges", C.c_int), ("range_lo", C.c_long * MAX_RANGES), ("range_hi", C.c_long * MAX_RANGES),
                  ("n_ffn", C.c_int), ("ffn1_off", C.c_uint32 * MAX_FFN), ("ffn2_off", C.c_uint32 * MAX_FFN),
-                 ("n_frag", C.c_int), ("frag", FragDesc * MAX_FRAG)])
+                 ("n_frag", C.c_int), ("frag", FragDesc * MAX_FRAG),
+                 ("seg_decoder", C.c_long), ("seg_cross", C.c_long), ("seg_modal", C.c_long * (MAX_LAYERS + 1))])
 
 
 SEGMENT_CALLBACK = C.CFUNCTYPE(None, C.c_int, C.c_void_p)

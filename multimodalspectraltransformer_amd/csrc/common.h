@@ -43,6 +43,9 @@ int mmst_stream_fork(hipStream_t from, hipStream_t to);
 // target-embedding launchers with explicit token strides (misc.hip); `clear`: optional fp32 slot set to zero
 int launch_trg_embed_fwd(const int64_t* tok, int tok_ld, int tok_bs, const float* embed, const float* pos, void* out,
                          int B, int T, float drop_p, uint32_t seed, hipStream_t stream, float* clear);
+// One stream of the library's own per device (created on first use, never destroyed): work that is neither on the
+// caller's critical path nor ordered with its second stream (layers.hip)
+hipStream_t mmst_side_stream();
 int launch_trg_embed_bwd(const int64_t* tok, int tok_ld, int tok_bs, const void* dout, float* d_embed, float* d_pos,
                          int B, int T, int V, float drop_p, uint32_t seed, hipStream_t stream);
 

@@ -374,7 +374,9 @@ hipEvent_t ring_event() {
 }
 // One stream of the library's own per device, created on first use: the decoder's backward keeps three chains busy
 // (activation gradients, the memory's dK / dV passes, parameter gradients) while most CUs idle.
-hipStream_t third_stream() {
+hipStream_t third_stream() { return mmst_side_stream(); }
+}  // namespace
+hipStream_t mmst_side_stream() {
   constexpr int MAX_DEV = 16;
   static hipStream_t streams[MAX_DEV];
   static bool made[MAX_DEV];
@@ -388,6 +390,7 @@ hipStream_t third_stream() {
   }
   return streams[dev];
 }
+namespace {
 
 // `to` (if not null) waits for everything enqueued on `from` so far (a marker on `from`); the event is handed back
 // on request.

@@ -116,8 +116,38 @@ int forward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed
                       ar->loss_grad_scale, st);
 }
 
+// AdamW over the active ranges inside [lo, hi) (it also leaves that part of the gradient zeroed for the next step)
+int adam_between(const mmst_step_plan* pl, const mmst_step_args* ar, long lo, long hi, hipStream_t s) {
+  long rlo[MMST_MAX_RANGES], rhi[MMST_MAX_RANGES];
+  int n = 0;
+  for (int i = 0; i < pl->n_ranges; ++i) {
+    const long a = pl->range_lo[i] > lo ? pl->range_lo[i] : lo, b = pl->range_hi[i] < hi ? pl->range_hi[i] : hi;
+    if (a < b) { rlo[n] = a; rhi[n] = b; ++n; }
+  }
+  if (n == 0) return MMST_OK;
+  return mmst_adamw_ranges(pl->P, pl->G, pl->M, pl->V, pl->Pb, n, rlo, rhi, ar->lr, ar->beta1, ar->beta2, ar->eps,
+                           ar->weight_decay, ar->adam_step, ar->grad_scale, 1, s);
+}
+// Optimizer beside backward: once every launch that adds to the gradient above offset `from` has been enqueued (on st,
+// wst or the library's side stream), that part [from, *done_from) is updated on the side stream, which waits for the
+// other two up to here; nothing in the rest of the step reads those weights again.  Off: MMST_ADAM_EARLY=0, a plan
+// without segment offsets, a step without optimizer.
+bool adam_early(const mmst_step_plan* pl, const mmst_step_args* ar) {
+  static const bool on = [] { const char* e = getenv("MMST_ADAM_EARLY"); return e ? atoi(e) != 0 : true; }();
+  return on && ar->adam_step > 0 && pl->seg_decoder > 0 && pl->M && pl->V && mmst_side_stream() != nullptr;
+}
+int adam_segment(const mmst_step_plan* pl, const mmst_step_args* ar, long from, long* done_from, hipStream_t st, hipStream_t wst) {
+  if (!adam_early(pl, ar) || from >= *done_from) return MMST_OK;
+  hipStream_t xst = mmst_side_stream();
+  RUN(mmst_stream_fork(st, xst));
+  RUN(mmst_stream_fork(wst, xst));
+  RUN(adam_between(pl, ar, from, *done_from, xst));
+  *done_from = from;
+  return MMST_OK;
+}
+
 int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embed_group* eg, const mmst_embed_shared* es,
-             hipStream_t st, hipStream_t wst) {
+             hipStream_t st, hipStream_t wst, long* adam_done_from) {
   const int B = pl->B, T = pl->T, L = pl->L, n = pl->n_groups, M = B * T;
   const int nl = pl->n_enc_layers, ndl = pl->n_dec_layers;
   const float dp = ar->drop_layers;
@@ -167,6 +197,7 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
   RUN(launch_trg_embed_bwd(ar->trg, 1, ar->trg_ld, pl->dtrg, pl->d_embed_trg, pl->d_pe_trg, B, T, pl->in_size,
                            ar->drop_embed, layer_seed(ar->step_seed, UID_TRG), wst));
   if (ar->on_segment) ar->on_segment(MMST_SEG_DECODER, ar->user);
+  RUN(adam_segment(pl, ar, pl->seg_decoder, adam_done_from, st, wst));
   // cross encoder
   {
     const mmst_enc_acts& la = pl->cross_a[nl - 1][0];
@@ -183,6 +214,7 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
                                        layer_seed(ar->step_seed, UID_CROSS + l), l < nl - 1 ? 2 : 0, st, wst));
   }
   if (ar->on_segment) ar->on_segment(MMST_SEG_CROSS, ar->user);
+  RUN(adam_segment(pl, ar, pl->seg_cross, adam_done_from, st, wst));
   // modality encoders: the top LayerNorm backward of every group reads its slice of the memory gradient
   {
     GemmBatch gb;
@@ -211,6 +243,7 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
     RUN(mmst_encoder_layer_bwd_streams(n, pl->modal_p[l], pl->modal_g[l], pl->modal_a[l], w, 16, dp,
                                        layer_seed(ar->step_seed, UID_MODAL + l), l < nl - 1 ? 2 : 0, st, wst));
     if (ar->on_segment) ar->on_segment(MMST_SEG_MODAL0 + l, ar->user);
+    if (l > 0) RUN(adam_segment(pl, ar, pl->seg_modal[l], adam_done_from, st, wst));   // depth 0 goes with the embeddings
   }
   // embeddings
   RUN(mmst_embed_bwd(n, eg, es, (const void* const*)pl->dxseq, st));
@@ -225,11 +258,12 @@ int backward(const mmst_step_plan* pl, const mmst_step_args* ar, const mmst_embe
   return mmst_stream_fork(wst, st);   // what follows on `stream` sees every gradient
 }
 
-int optimizer(const mmst_step_plan* pl, const mmst_step_args* ar, hipStream_t st, hipStream_t wst) {
+int optimizer(const mmst_step_plan* pl, const mmst_step_args* ar, hipStream_t st, hipStream_t wst, long done_from) {
   if (!pl->M || !pl->V) return MMST_ERR_ARG;
-  // one launch over every active range; it also leaves the gradient zeroed for the next step
-  RUN(mmst_adamw_ranges(pl->P, pl->G, pl->M, pl->V, pl->Pb, pl->n_ranges, pl->range_lo, pl->range_hi, ar->lr, ar->beta1,
-                        ar->beta2, ar->eps, ar->weight_decay, ar->adam_step, ar->grad_scale, 1, st));
+  // one launch over every active range that has not been updated beside backward; it also leaves the gradient zeroed
+  // for the next step.  `st` then waits for the side stream's updates.
+  RUN(adam_between(pl, ar, 0, done_from, st));
+  if (done_from < pl->range_hi[pl->n_ranges > 0 ? pl->n_ranges - 1 : 0]) RUN(mmst_stream_fork(mmst_side_stream(), st));
   // the transposed feed-forward weights are read by the backward pass only: refresh them on the second stream,
   // beside the next forward pass (the next backward waits for that stream first)
   RUN(mmst_stream_fork(st, wst));
@@ -273,8 +307,9 @@ int mmst_train_step(const mmst_step_plan* pl, const mmst_step_args* ar, void* st
           hipSuccess)
         return MMST_ERR_LAUNCH;
   RUN(forward(pl, ar, eg, &es, st, wst));
-  RUN(backward(pl, ar, eg, &es, st, wst));
-  if (ar->adam_step > 0) RUN(optimizer(pl, ar, st, wst));
+  long adam_done_from = pl->n_ranges > 0 ? pl->range_hi[pl->n_ranges - 1] : 0;   // nothing updated yet
+  RUN(backward(pl, ar, eg, &es, st, wst, &adam_done_from));
+  if (ar->adam_step > 0) RUN(optimizer(pl, ar, st, wst, adam_done_from));
   return MMST_OK;
 }
 

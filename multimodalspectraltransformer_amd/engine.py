@@ -823,6 +823,11 @@ class Engine:
         sp.n_frag = len(ar.frag_descs)
         for i, d in enumerate(ar.frag_array()[:sp.n_frag]):
             sp.frag[i] = d
+        mk = ar.marks
+        sp.seg_decoder, sp.seg_cross = mk["decoder"], mk["cross"]
+        for l in range(nl):
+            sp.seg_modal[l] = mk[f"modal_l{l}"]
+        sp.seg_modal[nl] = mk["cross"]
         pl._step_plan = sp
         pl._step_args = L.StepArgs()
         return sp
