@@ -27,9 +27,10 @@ with open(os.path.join(ROOT, "profiles", tag + "_sq_counters.md"), "w") as f:
             "the waves' lifetime during which the matrix pipe works for them; SQ_WAVE_CYCLES counts quad-cycles), *VALU per "
             "MFMA* = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA, *wait* = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked in "
             "s_waitcnt or a barrier), *issue stall* = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, *LDS conflicts* = "
-            "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, *waves per CU* = SQ_LEVEL_WAVES / SQ_BUSY_CYCLES (resident waves, "
-            "averaged over the cycles the CU is busy), *co-exec* = SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES.\n\n")
-    f.write("| kernel | avg us | % GPU time | MFMA busy | VALU per MFMA | wait | issue stall | LDS conflicts | waves per CU | co-exec |\n"
+            "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, *waves* = SQ_WAVES, the waves of a launch (256 CUs x 4 "
+            "SIMDs; SQ_LEVEL_WAVES, the resident-wave counter, reads 0 under this rocprofv3, so residency is what the "
+            "launch bounds say: one wave per SIMD for the feed-forward backward kernels, two for the forward ones), *co-exec* = SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES.\n\n")
+    f.write("| kernel | avg us | % GPU time | MFMA busy | VALU per MFMA | wait | issue stall | LDS conflicts | waves | co-exec |\n"
             "|---|---|---|---|---|---|---|---|---|---|\n")
     for r in stats:
         k = r["Name"]
@@ -38,10 +39,10 @@ with open(os.path.join(ROOT, "profiles", tag + "_sq_counters.md"), "w") as f:
         busy = val(p1, k, "SQ_VALU_MFMA_BUSY_CYCLES")
         row = [busy / (4 * wc), (va - mf) / mf if mf else float("nan"), val(p1, k, "SQ_WAIT_ANY") / wc,
                val(p2, k, "SQ_WAIT_INST_ANY") / wc, val(p2, k, "SQ_LDS_BANK_CONFLICT") / max(val(p2, k, "SQ_LDS_IDX_ACTIVE"), 1.0),
-               val(p2, k, "SQ_LEVEL_WAVES") / max(val(p1, k, "SQ_BUSY_CYCLES"), 1.0),
+               val(p1, k, "SQ_WAVES"),
                val(p2, k, "SQ_VALU_MFMA_COEXEC_CYCLES") / max(busy, 1.0)]
         f.write(f"| `{k[:70]}` | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} | "
-                + " | ".join(f"{x:.2f}" for x in row) + " |\n")
+                + " | ".join((f"{x:.0f}" if i == 5 else f"{x:.2f}") for i, x in enumerate(row)) + " |\n")
     f.write("\nRaw per-launch sums (pass 1 / pass 2):\n\n```\n")
     for r in stats:
         k = r["Name"]
