@@ -315,7 +315,6 @@ __global__ __launch_bounds__(NTHR) void dec_mid_kernel(const DecFusedFwd a) {
     if (tid + k * NTHR < MID_VEC) vec[tid + k * NTHR] = vv[k];
   lds_barrier();
   STAMP(1);
-#ifndef DEC_X_NOPRO
   {
     f32x4 acc[1][4];
     zero_acc<1>(acc);
@@ -326,7 +325,6 @@ __global__ __launch_bounds__(NTHR) void dec_mid_kernel(const DecFusedFwd a) {
   STAMP(2);
   ln_rows<false>(Zf, nullptr, res, vec + D, vec + 2 * D, (bf16*)s.z2 + (size_t)m0 * D, s.st2 + 2 * (size_t)m0, X2,
                  (bf16*)s.x2 + (size_t)m0 * D, T, tid, part == 0);
-#endif
   uint32_t rseed[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) rseed[mt] = attn_row_seed(a.seed_t + 4, (uint32_t)(m0 + mt * 16 + r));
@@ -335,12 +333,10 @@ __global__ __launch_bounds__(NTHR) void dec_mid_kernel(const DecFusedFwd a) {
   lds_barrier();   // x2 image complete (and the scratch, which the first chunk image overlays, has been read)
   STAMP(3);
   bf16* const Hg = (bf16*)s.h + (size_t)m0 * FF;
-#ifndef DEC_X_NOCHUNK
   ffn_chunk(acc2, w1A, w2A, X2, U, Hg, vec + 3 * D, c0, rseed, dp, thr, dscale, T, tid);
   STAMP(4);
   ffn_chunk(acc2, w1B, w2B, X2, U + TM * HS, Hg, vec + 3 * D + HC, c0 + 1, rseed, dp, thr, dscale, T, tid);
   STAMP(5);
-#endif
   float* const ws = a.ws + ((size_t)part * a.B * T + m0) * D;
   const int n = 16 * wave + 4 * g;
 #pragma unroll
@@ -489,7 +485,6 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
   // ---- causal self-attention, head_dim 8: wave w serves heads 2 w, 2 w + 1, two 32-query tiles each.  S^T = K Q^T
   // (v_mfma_f32_32x32x16_bf16, contraction zero-padded to 16) puts a query's 32 scores of a key tile into the 16
   // registers of its two lanes; the whole row (<= 64 keys) is in registers, so the softmax is one pass ----
-#ifndef DEC_X_NOATTN
   {
     const int r32 = lane & 31, hf = lane >> 5;
     const float scale2 = rsqrtf(8.0f) * LOG2E;
@@ -568,7 +563,6 @@ __global__ __launch_bounds__(NTHR) void dec_head_kernel(const DecFusedFwd a) {
       }
     }
   }
-#endif
   lds_barrier();
   STAMP(4);
   store_rows<D, XS>((bf16*)s.attn1 + (size_t)m0 * D, D, Oth, T, tid);
