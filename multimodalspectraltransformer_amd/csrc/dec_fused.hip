@@ -1297,6 +1297,10 @@ int launch_dec_bwd_mid(const DecFusedBwd& a, hipStream_t stream) {
 }
 int launch_dec_bwd_self(const DecFusedSelf& a, hipStream_t stream) {
   if (a.B < 1 || a.T < 1 || a.T > TM || !a.dqc || !a.qkv || !a.dqkv || !a.ft_qkv) return MMST_ERR_ARG;
+  if (!a.ft_cq || !a.dz2 || !a.z1 || !a.st1 || !a.g1 || !a.dg1 || !a.dbe1 || !a.dz1 || !a.ft_o || !a.attn1 || !a.lse1)
+    return MMST_ERR_ARG;
+  if (a.drop_p > 0.f && !a.dzd1) return MMST_ERR_ARG;
+  if (a.z3 && (!a.st3 || !a.g3 || !a.dg3 || !a.dbe3 || !a.dz3 || (a.drop_p > 0.f && !a.dzd3))) return MMST_ERR_ARG;
   if (a.z3) MMST_LAUNCH((dec_bwd_self_kernel<true>), dim3(a.B), dim3(NTHR), 0, stream, a);
   else if (a.dx) MMST_LAUNCH((dec_bwd_self_kernel<false>), dim3(a.B), dim3(NTHR), 0, stream, a);
   else return MMST_ERR_ARG;
