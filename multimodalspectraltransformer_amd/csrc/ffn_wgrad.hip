@@ -99,12 +99,19 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 #pragma unroll
     for (int t = 0; t < 8; ++t) { aw2[jt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; aw1[jt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   // bias gradients: db1[j] from the dh values of this lane (column li, 8 rows per step; the 4 lane quarters are
-  // added at the end); db2[n] = column sums of dz, by the first 128 threads of the first hidden block of each row split
+  // added at the end); db2[n] = column sums of dz: the first wave of hidden block t < 8 of each row split multiplies the
+  // dz^T fragment of n-tile t, which it loads anyway, with an all-ones operand (one more MFMA per step; every column of
+  // the result holds the sums).  (Summed by the first 128 threads of hidden block 0 with one LDS read per row and
+  // thread, that block's workgroups were the last to finish: 132 instead of 105 us for the launch.)
   float b1p[JT];
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) b1p[jt] = 0.f;
-  float b2p = 0.f;
-  const bool do_b2 = j0 == 0 && tid < DM;
+  // (wave-uniform by construction; read through a scalar so that the MFMA sits behind a branch, not an EXEC mask, which it would ignore)
+  const int b2_tile = __builtin_amdgcn_readfirstlane((wave == 0 && j0 < 8 * JC) ? j0 / JC : -1);
+  f32x4 b2acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   // this lane's share of a step's DMA: JT instructions per image, 4 image rows each, logical chunk sch[]
   int srow[JT], sch[JT];
@@ -182,11 +189,6 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           g[jt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[u][ks], wt[jt][ks], g[jt][u], 0, 0, 0);
-    if (do_b2) {
-#pragma unroll 8
-      for (int r = 0; r < STEP; ++r)
-        b2p += (float)*reinterpret_cast<const bf16*>(zimg + img_off(r, tid >> 3) + (tid & 7) * 2);
-    }
     bf16x8 hf[JT], dh[JT];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
           dh[jt] = o;
         }
       }
+      if (i < 8 && i == b2_tile) b2acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, b2acc, 0, 0, 0);       // dz^T 1
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt) {
         if (i < 8) aw2[jt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, hf[jt], aw2[jt][i], 0, 0, 0);          // dz^T h
@@ -306,7 +309,10 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
       v = xor32_sum(xor16_sum(v));
       if (q == 0) atomicAdd(pr.db1 + j0 + jw + jt * 16 + li, v);
     }
-    if (do_b2) atomicAdd(pr.db2 + tid, b2p);
+    if (b2_tile >= 0 && li == 0) {   // column 0 of the tile: n = 16 tile + 4 q + reg
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(pr.db2 + 16 * b2_tile + 4 * q + e, b2acc[e]);
+    }
   }
 }
 
