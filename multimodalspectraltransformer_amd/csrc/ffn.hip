@@ -21,6 +21,29 @@
 #include <string.h>
 #include <type_traits>
 
+#ifdef MMST_WG_LOG
+// timing build: one record per workgroup (start, end in 100 MHz ticks; kind << 32 | block; hardware ids)
+__device__ unsigned int g_wglog_n;
+__device__ unsigned long long g_wglog[4 * 32768];
+extern "C" int mmst_debug_wglog(unsigned long long* out, unsigned int* n) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wglog_n), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog), sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return -1;
+  return 0;
+}
+#define WGLOG_BEGIN() const unsigned long long wg_t0__ = wall_clock64()
+#define WGLOG_END(kind)                                                                                      \
+  if (threadIdx.x == 0) {                                                                                    \
+    const unsigned int ix__ = atomicAdd(&g_wglog_n, 1u) & 32767u;                                            \
+    g_wglog[4 * ix__] = wg_t0__;                                                                             \
+    g_wglog[4 * ix__ + 1] = wall_clock64();                                                                  \
+    g_wglog[4 * ix__ + 2] = ((unsigned long long)(kind) << 32) | blockIdx.x;                                 \
+    g_wglog[4 * ix__ + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+  }
+#else
+#define WGLOG_BEGIN()
+#define WGLOG_END(kind)
+#endif
+
 namespace {
 
 constexpr int DM = 128, FF = 2048, HC = 64, NCHUNK = FF / HC;
@@ -155,6 +178,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   typedef Shape<NW> S;
   constexpr int MT = S::MT, WD = S::WD, HD = S::HD, RSLOT = S::RSLOT;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * RSLOT];
+  WGLOG_BEGIN();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g = 0;
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_bwd_kernel(const
   } else {
     bwd_rows_epilogue<NW>(acc, pr, p0, pw0, lane, wave, tid, smem, smem + 2 * RSLOT);
   }
+  WGLOG_END(1);
 }
 
 // Sign words from a stored hidden activation, for the forward paths that do not produce them in the kernel (hidden
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
   __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT + FF * 4 + 9 * DM * 4];
   unsigned char* w1s = smem;             // 2 slots
   unsigned char* w2s = smem + 2 * SLOT;  // 2 slots
+  WGLOG_BEGIN();
   float* b1s = reinterpret_cast<float*>(smem + 4 * SLOT);
   float* vecs = b1s + FF;                // bias | gamma | beta of the final row epilogue, then of the prologue's,
                                          // then the bias of the chained linear layer (up to 384 columns)
@@ -760,6 +786,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ffn_fwd_kernel(const
       }
     }
   }
+  WGLOG_END(2);
 }
 
 int prepare(FfnBatch& b, bool bwd, int bpx) {

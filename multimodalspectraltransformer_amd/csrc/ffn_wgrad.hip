@@ -22,6 +22,17 @@
 #include "gemm_tile.h"
 #include <stdlib.h>
 
+#ifdef MMST_WG_LOG
+// timing build: one record per workgroup (start, end in 100 MHz ticks; block; hardware ids)
+__device__ unsigned int g_wglog2_n;
+__device__ unsigned long long g_wglog2[4 * 32768];
+extern "C" int mmst_debug_wglog2(unsigned long long* out, unsigned int* n) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wglog2_n), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog2), sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
 namespace {
 
 constexpr int DM = 128, FF = 2048, JC = 128, NJ = FF / JC, RS = 16, STEP = 32;
@@ -66,6 +77,9 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * 3 * IMG];
   static_assert(NBUF * 3 * IMG >= 128 * 129 * 4, "staging tile");
 
+#ifdef MMST_WG_LOG
+  const unsigned long long wg_t0 = wall_clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int gi = 0;
 #pragma unroll
@@ -314,6 +328,15 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
       for (int e = 0; e < 4; ++e) atomicAdd(pr.db2 + 16 * b2_tile + 4 * q + e, b2acc[e]);
     }
   }
+#ifdef MMST_WG_LOG
+  if (tid == 0) {
+    const unsigned int ix = atomicAdd(&g_wglog2_n, 1u) & 32767u;
+    g_wglog2[4 * ix] = wg_t0;
+    g_wglog2[4 * ix + 1] = wall_clock64();
+    g_wglog2[4 * ix + 2] = (3ull << 32) | blockIdx.x;
+    g_wglog2[4 * ix + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+  }
+#endif
 }
 
 }  // namespace

@@ -1,0 +1,76 @@
+"""Per-workgroup start / end of the feed-forward kernels in a training step: per launch the spread of the workgroups' durations, the
+compute units that hold two of them, and which weight-gradient workgroups share a unit with the slowest ones.
+Needs the library built by tools/wglog.sh build (kinds: 1 feed-forward backward, 2 forward, 3 weight gradients)."""
+import argparse, os, sys, ctypes as C
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from multimodalspectraltransformer_amd import synthetic as O, _lib as L
+from multimodalspectraltransformer_amd.train import TransformerMultiGPU
+MODE = "1H_HSQC_COSY_IR_MF_MW"
+cfg = O.default_config(training_mode=MODE)
+cfg.update(device="cuda:0", training_setup="pretraining", lr_finetuning=5e-5, model_save_dir="/tmp/mmst_bench",
+           gen_SMI_sequence=False, sampling_method="greedy", batch_size=64, save_model=False)
+config = argparse.Namespace(**cfg)
+torch.manual_seed(1234)
+tm = TransformerMultiGPU(config).to("cuda:0")
+tm.configure_optimizers()
+b = {k: v.cuda() for k, v in O.synthetic_batch(64, 1000, MODE).items()}
+for i in range(4):
+    tm.training_step(b, i)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (4 * 32768))()
+n = C.c_uint(0)
+assert L.lib().mmst_debug_wglog(buf, C.byref(n)) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+cnt = min(int(n.value), 32768)
+a = a[:cnt]
+buf2 = (C.c_ulonglong * (4 * 32768))()
+assert L.lib().mmst_debug_wglog2(buf2, C.byref(n)) == 0
+a2 = np.frombuffer(buf2, dtype=np.uint64).reshape(-1, 4)[:min(int(n.value), 32768)]
+a = np.concatenate([a, a2])
+cnt = len(a)
+a = a[np.argsort(a[:, 0])]
+# launches: a gap of > 5 us between consecutive starts of the same kind separates them
+recs = [(int(r[0]), int(r[1]), int(r[2] >> 32), int(r[2] & 0xFFFFFFFF), int(r[3] >> 32) & 0xF, int(r[3] & 0xFFFFFFFF)) for r in a]
+launches = []
+for r in recs:
+    same = [l for l in launches[-3:] if l[0][2] == r[2]]
+    if same and r[0] - same[-1][-1][0] < 3000 and r[0] < same[-1][0][0] + 30000:
+        same[-1].append(r)
+    else:
+        launches.append([r])
+print("records", cnt, "launches", len(launches))
+for ln in launches[-40:]:
+    t0 = min(r[0] for r in ln); t1 = max(r[1] for r in ln)
+    st = np.array([(r[0] - t0) / 100.0 for r in ln]); en = np.array([(r[1] - t0) / 100.0 for r in ln]); du = en - st
+    cu = {}
+    for r in ln:
+        hw = r[5]; key = (r[4], (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)
+        cu[key] = cu.get(key, 0) + 1
+    print("t %7.1f kind %d wgs %3d span %6.1f us | start p50 %5.1f max %5.1f | dur p10 %5.1f p50 %5.1f p90 %5.1f max %5.1f | end p50 %5.1f p90 %5.1f | CUs %d, with 2+: %d"
+          % ((t0 - launches[-40][0][0]) / 100.0, ln[0][2], len(ln), (t1 - t0) / 100.0, np.median(st), st.max(), np.percentile(du, 10), np.median(du), np.percentile(du, 90), du.max(),
+             np.median(en), np.percentile(en, 90), len(cu), sum(1 for v in cu.values() if v > 1)))
+print("slowest workgroups of the last backward launches (block, xcc, se, cu, start, dur):")
+for ln in [l for l in launches if l[0][2] == 1][-8:]:
+    t0 = min(r[0] for r in ln)
+    top = sorted(ln, key=lambda r: r[0] - r[1])[:6]
+    print(len(ln), [(r[3], r[4], (r[5] >> 13) & 7, (r[5] >> 8) & 15, round((r[0] - t0) / 100.0, 1), round((r[1] - r[0]) / 100.0, 1)) for r in top])
+print("co-residents of the slowest backward workgroups (modal launches):")
+k1 = [l for l in launches if l[0][2] == 1 and len(l) == 228][-4:]
+k3 = [l for l in launches if l[0][2] == 3]
+for ln in k1:
+    t0 = min(r[0] for r in ln)
+    w = [l for l in k3 if abs(l[0][0] - t0) < 3000]
+    if not w: continue
+    w = w[0]
+    key = lambda r: (r[4], (r[5] >> 8) & 0xFF)
+    on = {}
+    for r in w: on.setdefault(key(r), []).append(r)
+    top = sorted(ln, key=lambda r: r[0] - r[1])
+    def desc(r):
+        o = on.get(key(r), [])
+        return (r[3], round((r[1] - r[0]) / 100.0, 1), [(x[3], round((x[0] - t0) / 100.0, 1), round((x[1] - x[0]) / 100.0, 1)) for x in o])
+    print(" slow:", [desc(r) for r in top[:5]])
+    print(" mid: ", [desc(r) for r in top[110:114]])
+    print(" fast:", [desc(r) for r in top[-4:]])
