@@ -7,7 +7,7 @@
 // dh is recomputed here from dz and the saved hidden activation, so the backward pass never writes or re-reads a
 // [rows][2048] gradient: the only large HBM stream of this kernel is ONE read of h.
 //
-// Decomposition: a workgroup owns 128 hidden columns j and one row split (about 2300 rows; 16 splits at 37248 rows); each of its waves
+// Decomposition: a workgroup owns 128 hidden columns j and one row split (2000 to 3100 rows; 12 splits at 37248 rows); each of its waves
 // owns 16 of those columns for everything: g and dh for them, the [128 n][16 j] slice of dW2 and the [16 j][128 k]
 // slice of dW1, both in accumulators for the workgroup's whole life; they leave through LDS-staged fp32 atomics of
 // 256 contiguous bytes at the end (one add per gradient element and row split).  Rows are walked 32 at a time: the dz, h
@@ -87,11 +87,16 @@ __global__ __launch_bounds__(512 / JT, JT) void ffn_wgrad_kernel(const FfnWgradB
     if (i < batch.n && (int)blockIdx.x >= batch.p[i].tile_begin) gi = i;
   const FfnWgradProb& pr = batch.p[gi];
   const int local = (int)blockIdx.x - pr.tile_begin;
-  const int nrs = pr.rs;                                    // row splits of this problem: a power of two <= RS
+  const int nrs = pr.rs;                                    // row splits of this problem, <= RS
   // consecutive workgroup ids rotate over the 8 XCDs: ids equal mod 8 (mod nrs when there are fewer splits) share a
   // row split, so its dz / x tiles are fetched into one L2 (8 / nrs of them)
-  const int rs = nrs == RS ? ((local & 7) | (((local >> 3) & 1) << 3)) : (local & (nrs - 1));
-  const int j0 = (nrs == RS ? (local >> 4) : (local / nrs)) * JC;
+  // (12 splits: an XCD holds 3 splits x 8 hidden blocks; any other count: no XCD affinity)
+  int rs, jb;
+  if (nrs == RS) { rs = (local & 7) | (((local >> 3) & 1) << 3); jb = local >> 4; }
+  else if (nrs == 12) { const int x = local & 7, idx = local >> 3; rs = 3 * (x & 3) + idx % 3; jb = 8 * (x >> 2) + idx / 3; }
+  else if ((nrs & (nrs - 1)) == 0) { rs = local & (nrs - 1); jb = local / nrs; }
+  else { rs = local % nrs; jb = local / nrs; }
+  const int j0 = jb * JC;
   const int M = pr.M;
   const int nsteps = (M + STEP - 1) / STEP;
   const int s0 = (int)((long)nsteps * rs / nrs), s1 = (int)((long)nsteps * (rs + 1) / nrs);
@@ -353,6 +358,15 @@ int launch_ffn_wgrad(FfnWgradBatch& b, hipStream_t stream) {
     // against 131, and 7.93 against 7.69 ms per training step; 1200 or 4700 rows per split measure 7.73 / 7.86 ms.)
     int rs = 1;
     while (rs < RS && p.M > rs * 2328) rs *= 2;
+    // 16 x 16 workgroups want every CU, but the feed-forward backward kernel that runs beside this one has 257..320
+    // row tiles for such a problem and puts two of its workgroups on the CUs beyond 256, which then cannot take a
+    // workgroup of this kernel as well: the surplus ones started when that kernel ended (35 of 256, 85 us late, at 37248
+    // rows).  Twelve splits = 192 workgroups all start at once, and a quarter of the fp32 atomics is gone
+    // (6.30 -> 6.26 ms per training step; 10, 13 and 14 splits measure like 16).  MMST_WGRAD_SPLITS overrides.
+    const int tiles = (p.M + 127) / 128;
+    if (rs == RS && tiles > 256 && tiles <= 320) rs = 12;
+    static const int forced = [] { const char* e = getenv("MMST_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+    if (forced > 0 && forced <= RS && p.M > 30000) rs = forced;
     p.rs = rs;
     p.tile_begin = total;
     total += NJ * rs;

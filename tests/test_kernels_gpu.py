@@ -375,7 +375,7 @@ def test_ffn_fwd_with_prologue_and_chained_projection(M, groups):
             assert torch.isnan(qkv.float()).all()   # not produced: the caller launches that projection
 
 
-@pytest.mark.parametrize("M,groups,p", [(1024, 1, 0.0), (1000, 2, 0.1), (77, 1, 0.1), (8256, 1, 0.1)])
+@pytest.mark.parametrize("M,groups,p", [(1024, 1, 0.0), (1000, 2, 0.1), (77, 1, 0.1), (8256, 1, 0.1), (33000, 1, 0.1), (37248, 1, 0.1)])
 def test_ffn_wgrad_recompute(M, groups, p, wgrad_shape):
     """dW1/db1/dW2/db2 of the feed-forward block from (dz, h, x, W2^T) with dh recomputed in the kernel,
     accumulated on top of existing gradient content, against fp32 torch math."""
