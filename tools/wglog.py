@@ -25,10 +25,11 @@ assert L.lib().mmst_debug_wglog(buf, C.byref(n)) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 cnt = min(int(n.value), 32768)
 a = a[:cnt]
-buf2 = (C.c_ulonglong * (4 * 32768))()
-assert L.lib().mmst_debug_wglog2(buf2, C.byref(n)) == 0
-a2 = np.frombuffer(buf2, dtype=np.uint64).reshape(-1, 4)[:min(int(n.value), 32768)]
-a = np.concatenate([a, a2])
+for fn in ("mmst_debug_wglog2", "mmst_debug_wglog3"):
+    buf2 = (C.c_ulonglong * (4 * 32768))()
+    assert getattr(L.lib(), fn)(buf2, C.byref(n)) == 0
+    a2 = np.frombuffer(buf2, dtype=np.uint64).reshape(-1, 4)[:min(int(n.value), 32768)].copy()
+    a = np.concatenate([a, a2])
 cnt = len(a)
 a = a[np.argsort(a[:, 0])]
 # launches: a gap of > 5 us between consecutive starts of the same kind separates them
@@ -41,7 +42,7 @@ for r in recs:
     else:
         launches.append([r])
 print("records", cnt, "launches", len(launches))
-for ln in launches[-40:]:
+for ln in launches[-64:]:
     t0 = min(r[0] for r in ln); t1 = max(r[1] for r in ln)
     st = np.array([(r[0] - t0) / 100.0 for r in ln]); en = np.array([(r[1] - t0) / 100.0 for r in ln]); du = en - st
     cu = {}
@@ -49,7 +50,7 @@ for ln in launches[-40:]:
         hw = r[5]; key = (r[4], (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)
         cu[key] = cu.get(key, 0) + 1
     print("t %7.1f kind %d wgs %3d span %6.1f us | start p50 %5.1f max %5.1f | dur p10 %5.1f p50 %5.1f p90 %5.1f max %5.1f | end p50 %5.1f p90 %5.1f | CUs %d, with 2+: %d"
-          % ((t0 - launches[-40][0][0]) / 100.0, ln[0][2], len(ln), (t1 - t0) / 100.0, np.median(st), st.max(), np.percentile(du, 10), np.median(du), np.percentile(du, 90), du.max(),
+          % ((t0 - launches[-64][0][0]) / 100.0, ln[0][2], len(ln), (t1 - t0) / 100.0, np.median(st), st.max(), np.percentile(du, 10), np.median(du), np.percentile(du, 90), du.max(),
              np.median(en), np.percentile(en, 90), len(cu), sum(1 for v in cu.values() if v > 1)))
 print("slowest workgroups of the last backward launches (block, xcc, se, cu, start, dur):")
 for ln in [l for l in launches if l[0][2] == 1][-8:]:
@@ -74,3 +75,28 @@ for ln in k1:
     print(" slow:", [desc(r) for r in top[:5]])
     print(" mid: ", [desc(r) for r in top[110:114]])
     print(" fast:", [desc(r) for r in top[-4:]])
+
+print("attention backward launches: resident workgroups every 10 us; durations of the dK/dV blocks (first half of the grid) and dQ blocks")
+for ln in [l for l in launches if l[0][2] in (4, 5)][-12:]:
+    t0 = min(r[0] for r in ln); t1 = max(r[1] for r in ln)
+    nb = max(r[3] for r in ln) + 1
+    kv = np.array([(r[1] - r[0]) / 100.0 for r in ln if r[3] < nb // 2]); qq = np.array([(r[1] - r[0]) / 100.0 for r in ln if r[3] >= nb // 2])
+    occ = [sum(1 for r in ln if r[0] <= t0 + 1000 * k < r[1]) for k in range(int((t1 - t0) / 1000) + 1)]
+    print("kind %d wgs %4d span %6.1f us | kv p50 %5.1f max %5.1f | q p50 %5.1f max %5.1f | resident %s" % (ln[0][2], len(ln), (t1 - t0) / 100.0, np.median(kv), kv.max(), np.median(qq), qq.max(), occ))
+print("attention workgroups that start within 10 us of their launch: how many sit on a CU that holds a weight-gradient workgroup at that moment")
+allw = [r for l in launches if l[0][2] == 3 for r in l]
+allb = [r for l in launches if l[0][2] == 1 for r in l]
+key = lambda r: (r[4], (r[5] >> 8) & 0xFF)
+for ln in [l for l in launches if l[0][2] in (4, 5)][-8:]:
+    t0 = min(r[0] for r in ln)
+    early = [r for r in ln if r[0] < t0 + 1000]
+    wres = {}
+    for w in allw:
+        if w[0] <= t0 + 500 < w[1]: wres[key(w)] = wres.get(key(w), 0) + 1
+    bres = {}
+    for w in allb:
+        if w[0] <= t0 + 500 < w[1]: bres[key(w)] = bres.get(key(w), 0) + 1
+    cus = {}
+    for r in early: cus[key(r)] = cus.get(key(r), 0) + 1
+    print("kind %d: %d early workgroups on %d CUs; weight-gradient workgroups resident on %d CUs, feed-forward backward on %d; early ones on a CU with a weight-gradient workgroup: %d"
+          % (ln[0][2], len(early), len(cus), len(wres), len(bres), sum(1 for r in early if key(r) in wres)))
