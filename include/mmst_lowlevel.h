@@ -124,7 +124,7 @@ typedef struct {
   const void* dZ; const void* H; const void* X; const void* W2T;
   float* dW1; float* db1; float* dW2; float* db2;
   int M; float drop_p;
-  int tile_begin, rs;                 /* launcher */
+  int tile_begin, rs; float skew;     /* launcher */
 } mmst_ffn_wgrad_prob;
 typedef struct { int n; mmst_ffn_wgrad_prob p[6]; } mmst_ffn_wgrad_batch;
 int mmst_ffn_wgrad(const mmst_ffn_wgrad_batch* batch, void* stream);

@@ -68,7 +68,7 @@ class FfnBatch(C.Structure):
 
 class FfnWgradProb(C.Structure):
     _fields_ = _P8 = [(n, C.c_void_p) for n in ("dZ", "H", "X", "W2T", "dW1", "db1", "dW2", "db2")] + [
-        ("M", C.c_int), ("drop_p", C.c_float), ("tile_begin", C.c_int), ("rs", C.c_int)]
+        ("M", C.c_int), ("drop_p", C.c_float), ("tile_begin", C.c_int), ("rs", C.c_int), ("skew", C.c_float)]
 
 
 class FfnWgradBatch(C.Structure):

@@ -23,7 +23,8 @@ static_assert(sizeof(mmst_ffn_prob) == sizeof(FfnProb) && sizeof(mmst_ffn_batch)
               offsetof(mmst_ffn_prob, hsplit) == offsetof(FfnProb, hsplit) && offsetof(mmst_ffn_prob, Wp) == offsetof(FfnProb, Wp) &&
               offsetof(mmst_ffn_prob, pre) == offsetof(FfnProb, pre) && offsetof(mmst_ffn_prob, nq) == offsetof(FfnProb, nq), "ffn ABI");
 static_assert(sizeof(mmst_ffn_wgrad_prob) == sizeof(FfnWgradProb) && sizeof(mmst_ffn_wgrad_batch) == sizeof(FfnWgradBatch) &&
-              offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M) && offsetof(mmst_ffn_wgrad_prob, rs) == offsetof(FfnWgradProb, rs), "ffn weight-gradient ABI");
+              offsetof(mmst_ffn_wgrad_prob, M) == offsetof(FfnWgradProb, M) && offsetof(mmst_ffn_wgrad_prob, rs) == offsetof(FfnWgradProb, rs) &&
+              offsetof(mmst_ffn_wgrad_prob, skew) == offsetof(FfnWgradProb, skew), "ffn weight-gradient ABI");
 static_assert(MMST_GEMM_MAX_GROUPS == GEMM_MAX_GROUPS && MMST_EPI_ATOMIC == EPI_ATOMIC && MMST_GF_OUT_F32 == GF_OUT_F32, "gemm ABI");
 
 extern "C" {

@@ -62,7 +62,8 @@ struct FfnWgradProb {
   int M;
   float drop_p;
   int tile_begin;      // filled by the launcher: first workgroup of this problem
-  int rs;              // filled by the launcher: row splits (1, 2, 4, 8 or 16), about 2300 rows each
+  int rs;              // filled by the launcher: row splits (at most 16), 2000 to 3100 rows each on average
+  float skew;          // filled by the launcher: the splits' sizes grow from (1 - skew) to (1 + skew) of the average
 };
 struct FfnWgradBatch {
   int n;
