@@ -16,8 +16,8 @@
 // and the contraction index of the two gradient GEMMs is the step's 32 rows in exactly that register order
 // (k = 0..3 -> rows 4q..4q+3, k = 4..7 -> rows 16+4q..16+4q+3 for lane quarter q), so the masked g IS the
 // operand fragment of dW1, and the transposing LDS reads of h, dz and x use the same row order.
-// Workgroups of one row split sit on one XCD (consecutive ids rotate over the 8 XCDs), so the dz / x tiles they
-// share are served by that L2.
+// Workgroups of one row split sit on one XCD (two with 12 splits; consecutive ids rotate over the 8 XCDs), so the
+// dz / x tiles they share are served by that L2.  The splits' sizes differ on purpose (FfnWgradProb::skew).
 #include "ffn.h"
 #include "gemm_tile.h"
 #include <stdlib.h>
