@@ -618,10 +618,38 @@ __device__ __forceinline__ void attn_q_body(const AttnBatch& batch, int block, u
   }
 }
 
+#ifdef MMST_WG_LOG
+}  // namespace
+// timing build: one record per workgroup (start, end in 100 MHz ticks; kind << 32 | block; hardware ids)
+__device__ unsigned int g_wglog3_n;
+__device__ unsigned long long g_wglog3[4 * 32768];
+extern "C" int mmst_debug_wglog3(unsigned long long* out, unsigned int* n) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wglog3_n), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog3), sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return -1;
+  return 0;
+}
+namespace {
+#endif
+#ifdef MMST_WG_LOG
+#define ATTN_WGLOG_END(kind)                                                                                  \
+  if (threadIdx.x == 0) {                                                                                    \
+    const unsigned int ix = atomicAdd(&g_wglog3_n, 1u) & 32767u;                                             \
+    g_wglog3[4 * ix] = wg_t0;                                                                                \
+    g_wglog3[4 * ix + 1] = wall_clock64();                                                                   \
+    g_wglog3[4 * ix + 2] = ((unsigned long long)(kind) << 32) | blockIdx.x;                                  \
+    g_wglog3[4 * ix + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+  }
+#endif
 template <int HD, bool CAUSAL, bool BWD>
 __global__ void attn_q_kernel(const AttnBatch batch) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[q_smem_bytes<HD, BWD>()];
+#ifdef MMST_WG_LOG
+  const unsigned long long wg_t0 = wall_clock64();
+#endif
   attn_q_body<HD, CAUSAL, BWD>(batch, (int)blockIdx.x, smem);
+#ifdef MMST_WG_LOG
+  ATTN_WGLOG_END(BWD ? 8 : (HD == 32 ? 6 : 7));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1000,18 +1028,6 @@ __global__ void attn_bwd_self_kernel(const AttnBatch batch) {
 // both) in ONE launch: blocks [0, nblocks) run the dK/dV pass (with its own delta), blocks [nblocks, 2 nblocks) the dQ
 // pass.  No launch boundary between the passes, and the tail of one overlaps the head of the other: -0.03 ms per training
 // step at 64 molecules (dQ blocks first: -0.02 less; the two kinds interleaved block by block: +0.36 ms).
-#ifdef MMST_WG_LOG
-}  // namespace
-// timing build: one record per workgroup (start, end in 100 MHz ticks; kind << 32 | block; hardware ids)
-__device__ unsigned int g_wglog3_n;
-__device__ unsigned long long g_wglog3[4 * 32768];
-extern "C" int mmst_debug_wglog3(unsigned long long* out, unsigned int* n) {
-  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wglog3_n), 4) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog3), sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return -1;
-  return 0;
-}
-namespace {
-#endif
 template <int HD, bool CAUSAL>
 __global__ void attn_bwd_both_kernel(const AttnBatch batch, int nblocks) {
   constexpr int SM = kv_smem_bytes<HD>() > q_smem_bytes<HD, true>() ? kv_smem_bytes<HD>() : q_smem_bytes<HD, true>();
@@ -1022,13 +1038,7 @@ __global__ void attn_bwd_both_kernel(const AttnBatch batch, int nblocks) {
   if ((int)blockIdx.x < nblocks) attn_kv_body<HD, CAUSAL, true>(batch, (int)blockIdx.x, smem);
   else attn_q_body<HD, CAUSAL, true>(batch, (int)blockIdx.x - nblocks, smem);
 #ifdef MMST_WG_LOG
-  if (threadIdx.x == 0) {
-    const unsigned int ix = atomicAdd(&g_wglog3_n, 1u) & 32767u;
-    g_wglog3[4 * ix] = wg_t0;
-    g_wglog3[4 * ix + 1] = wall_clock64();
-    g_wglog3[4 * ix + 2] = ((unsigned long long)(HD == 32 ? 4 : 5) << 32) | blockIdx.x;
-    g_wglog3[4 * ix + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
-  }
+  ATTN_WGLOG_END(HD == 32 ? 4 : 5);
 #endif
 }
 

@@ -100,3 +100,12 @@ for ln in [l for l in launches if l[0][2] in (4, 5)][-8:]:
     for r in early: cus[key(r)] = cus.get(key(r), 0) + 1
     print("kind %d: %d early workgroups on %d CUs; weight-gradient workgroups resident on %d CUs, feed-forward backward on %d; early ones on a CU with a weight-gradient workgroup: %d"
           % (ln[0][2], len(early), len(cus), len(wres), len(bres), sum(1 for r in early if key(r) in wres)))
+
+# (the attention log holds 32768 records, less than a step's attention launches: only the launches near the end of the
+# last step are complete; a forward launch listed here may have lost records to later ones)
+print("attention forward launches still in the log (kind 6: head_dim 32, 7: head_dim 8): resident workgroups every 5 us")
+for ln in [l for l in launches if l[0][2] in (6, 7)][-8:]:
+    t0 = min(r[0] for r in ln); t1 = max(r[1] for r in ln)
+    du = np.array([(r[1] - r[0]) / 100.0 for r in ln])
+    occ = [sum(1 for r in ln if r[0] <= t0 + 500 * k < r[1]) for k in range(int((t1 - t0) / 500) + 1)]
+    print("kind %d wgs %4d span %6.1f us | dur p10 %5.1f p50 %5.1f p90 %5.1f max %5.1f | resident %s" % (ln[0][2], len(ln), (t1 - t0) / 100.0, np.percentile(du, 10), np.median(du), np.percentile(du, 90), du.max(), occ))
