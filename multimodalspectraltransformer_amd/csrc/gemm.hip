@@ -22,8 +22,23 @@
 
 namespace {
 
+#ifdef MMST_WG_LOG
+}  // namespace
+// timing build: one record per workgroup of the LayerNorm-backward GEMM (start, end in 100 MHz ticks; kind << 32 | block; hardware ids)
+__device__ unsigned int g_wglog4_n;
+__device__ unsigned long long g_wglog4[4 * 32768];
+extern "C" int mmst_debug_wglog4(unsigned long long* out, unsigned int* n) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wglog4_n), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog4), sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return -1;
+  return 0;
+}
+namespace {
+#endif
 template <int EPI, bool PT, bool QT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch) {
+#ifdef MMST_WG_LOG
+  const unsigned long long wg_t0 = wall_clock64();
+#endif
   constexpr bool ROWEPI = (EPI == EPI_LN || EPI == EPI_LNBWD);
   constexpr int MT = (ROWEPI ? 2 : 4) * 4 / NW;
   constexpr int NT = ROWEPI ? 8 : 4;
@@ -240,6 +255,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmBatch batch)
   if constexpr (EPI == EPI_LNBWD) {
     if constexpr (ROWEPI) epi_lnbwd<NW>(acc, pr, p0, pw0, lane, wave, tid, smem);
   }
+#ifdef MMST_WG_LOG
+  if (EPI == EPI_LNBWD && threadIdx.x == 0) {
+    const unsigned int ix = atomicAdd(&g_wglog4_n, 1u) & 32767u;
+    g_wglog4[4 * ix] = wg_t0;
+    g_wglog4[4 * ix + 1] = wall_clock64();
+    g_wglog4[4 * ix + 2] = (9ull << 32) | blockIdx.x;
+    g_wglog4[4 * ix + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+  }
+#endif
 }
 
 

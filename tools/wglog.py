@@ -1,6 +1,7 @@
 """Per-workgroup start / end of the feed-forward kernels in a training step: per launch the spread of the workgroups' durations, the
 compute units that hold two of them, and which weight-gradient workgroups share a unit with the slowest ones.
-Needs the library built by tools/wglog.sh build (kinds: 1 feed-forward backward, 2 forward, 3 weight gradients)."""
+Needs the library built by tools/wglog.sh build (kinds: 1 feed-forward backward, 2 forward, 3 weight gradients, 4 / 5 attention backward, 6 / 7 / 8 attention forward / dQ,
+9 the in_proj-backward GEMM with its LayerNorm-backward epilogue)."""
 import argparse, os, sys, ctypes as C
 import numpy as np
 import torch
@@ -25,7 +26,7 @@ assert L.lib().mmst_debug_wglog(buf, C.byref(n)) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 cnt = min(int(n.value), 32768)
 a = a[:cnt]
-for fn in ("mmst_debug_wglog2", "mmst_debug_wglog3"):
+for fn in ("mmst_debug_wglog2", "mmst_debug_wglog3", "mmst_debug_wglog4"):
     buf2 = (C.c_ulonglong * (4 * 32768))()
     assert getattr(L.lib(), fn)(buf2, C.byref(n)) == 0
     a2 = np.frombuffer(buf2, dtype=np.uint64).reshape(-1, 4)[:min(int(n.value), 32768)].copy()
